@@ -1,0 +1,51 @@
+"""Builds libsphfluid.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+No torch extension machinery: the product is a plain C-ABI shared library (include/sphfluid.h).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsphfluid.so")
+SOURCES = ["sphfluid.hip"]
+HEADERS = ["sph_device.h", "sph_sort.h", "sph_neighbors.h", "sph_stream.h",
+           os.path.join("..", "..", "include", "sphfluid.h")]
+
+# -ffp-contract=off: the neighbour predicates must round exactly like the reference's
+# non-contracted fp32 (FluidSPHByCPUSystem.cs:72,97,156,219); fused ops are written explicitly.
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+               "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math",
+               "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc()] + HIPCC_FLAGS + list(extra_flags) + \
+        [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True,
+          extra_flags=[a for a in sys.argv[1:] if a.startswith("-R") or a.startswith("-save")])

@@ -1,0 +1,102 @@
+// sph_device.h -- device-side data layout shared by the gfx950 kernels of libsphfluid.so.
+//
+// Data layout in HBM (DESIGN.md "Data layout"): the fluid state lives in *sorted order* (stable by
+// dense cell key, ties by ECS id) and stays there from step to step:
+//   posm[N]  float4  x, y, z, mass (= 1f / InverseMass, FluidSPHByCPUSystem.cs:54,165)
+//   velq[N]  float4  vx, vy, vz, q = p / (rho*rho)   (q written by the density kernel)
+//   mat[N]   u32     index into the material table (per-particle constants, deduplicated)
+//   oid[N]   u32     ECS id of the particle in this slot (= the sorted permutation)
+//   rho[N], prs[N] f32, force[N] float4
+// Boundary particles are static: sorted once into bposm[B] (x, y, z, mass) with their own table.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SPH_WAVE 64
+
+// Periodic cell table (see SphGrid in include/sphfluid.h)
+struct GridDesc {
+    int ox, oy, oz;
+    int gx, gy, gz;
+    float cellSize;
+    int cells;
+};
+
+// Per-material constants, computed once on the host in float32 in the reference's evaluation
+// order (FluidSPHByCPUSystem.cs:53-60,133-135), so that the device and the oracle use identical
+// thresholds:  h = radius*rate, h2 = h*h (== pow(h,2)),
+//   thrF = the least float t with sqrt_rn(t) >= h, so that  length(v) < h  <=>  dot(v,v) < thrF
+//   (the force pass's predicate, :156,219, without a per-pair correctly rounded sqrt).
+struct Mat {
+    float h, h2, thrF, poly6;      // poly6 = mass*315/(64*PI*h^9)
+    float restDensity, gasConstant, viscosity, mass;
+    float invMass, radius, spiky;  // spiky = 45/(PI*h^6)
+    float pad;
+};
+
+// Box collider in the form the integrate kernel reads (row-major rotation, world = R*local)
+struct DevBox {
+    float c[3];
+    float R[9];
+    float he[3];
+    float lv[3];
+    float av[3];
+    float invMass;
+    float invI[3];
+    float restitution;
+    int dynamic;
+};
+
+__device__ __forceinline__ int wrap_cell(int c, int g)
+{
+    int m = c % g;
+    return m < 0 ? m + g : m;
+}
+
+// FluidSPHUtils.Quantize, :236-243: (int)floor(p / size), true IEEE division
+__device__ __forceinline__ int quantize1(float p, float size)
+{
+    return (int)floorf(p / size);
+}
+
+// FluidSPHUtils.Hash, :246-261: FNV-1 over the 12 little-endian bytes of (x,y,z)
+__device__ __forceinline__ uint32_t fnv1_cell(int x, int y, int z)
+{
+    uint32_t hash = 2166136261u;
+    const int p[3] = {x, y, z};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            hash *= 16777619u;
+            hash ^= (uint32_t)(p[i] >> (8 * j)) & 0xffu;
+        }
+    }
+    return hash;
+}
+
+__device__ __forceinline__ uint32_t dense_key(int cx, int cy, int cz, const GridDesc &g)
+{
+    int x = wrap_cell(cx - g.ox, g.gx);
+    int y = wrap_cell(cy - g.oy, g.gy);
+    int z = wrap_cell(cz - g.oz, g.gz);
+    return (uint32_t)((z * g.gy + y) * g.gx + x);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// popcount of the set bits of mask below this lane
+__device__ __forceinline__ int mbcnt64(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// wave-uniform broadcast of lane `src` (src must be wave-uniform)
+__device__ __forceinline__ float bcast_f(float v, int src)
+{
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }

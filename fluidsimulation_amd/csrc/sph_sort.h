@@ -1,0 +1,191 @@
+// sph_sort.h -- wavefront-ballot / LDS radix sort (stable, LSD, 8-bit digits) and the cell
+// (start,end) table.  Replaces the reference's bitonic network (FluidSolver.compute:47-83 driven
+// by FluidSPHByGPUSystem.cs:279-299: log2P(log2P+1)/2 dispatches of compare-and-swap over global
+// memory) and its ClearTable / MapTable kernels (FluidSolver.compute:85-112).
+//
+// Per 8-bit pass, three launches over tiles of 4096 keys:
+//   k_radix_hist     per-tile digit counts (LDS sub-histograms)            reads 4 B/key
+//   k_radix_scan     per-digit exclusive scan over tiles + digit totals    (small)
+//   k_radix_scatter  stable rank by wave ballots (64-wide match-any), per-wave digit counters in
+//                    LDS, tile sorted by digit in LDS, coalesced write-out  reads 8, writes 8 B/key
+// Algorithmic bytes: 20 B per key per pass.  HBM-bound; no MFMA.
+#pragma once
+#include "sph_device.h"
+
+#define RS_THREADS 256
+#define RS_WAVES 4
+#define RS_ITEMS 16
+#define RS_TILE (RS_THREADS * RS_ITEMS)
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; tmp: 4 words of LDS
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *tmp,
+                                                        uint32_t *total)
+{
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan_u32(v, lane);
+    if (lane == 63) tmp[w] = incl;
+    __syncthreads();
+    uint32_t basew = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; i++) {
+        uint32_t t = tmp[i];
+        if (i < w) basew += t;
+        tot += t;
+    }
+    __syncthreads();
+    if (total) *total = tot;
+    return basew + incl - v;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t *__restrict__ keys,
+                                                           int n, int shift,
+                                                           uint32_t *__restrict__ hist,
+                                                           int nblocks)
+{
+    __shared__ uint32_t h[256 * 8]; // [digit][sub]: 8 sub-histograms spread over 8 banks
+    const int tid = threadIdx.x, sub = tid & 7;
+    for (int i = tid; i < 256 * 8; i += RS_THREADS) h[i] = 0;
+    __syncthreads();
+    const long base = (long)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        long i = base + k * RS_THREADS + tid;
+        if (i < n) atomicAdd(&h[((keys[i] >> shift) & 255u) * 8 + sub], 1u);
+    }
+    __syncthreads();
+    uint32_t c = 0;
+#pragma unroll
+    for (int s = 0; s < 8; s++) c += h[tid * 8 + s];
+    hist[(size_t)tid * nblocks + blockIdx.x] = c;
+}
+
+// one block per digit: in-place exclusive scan of that digit's row of tile counts
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scan(uint32_t *__restrict__ hist,
+                                                           uint32_t *__restrict__ rowTotal,
+                                                           int nblocks)
+{
+    __shared__ uint32_t tmp[RS_WAVES];
+    uint32_t *row = hist + (size_t)blockIdx.x * nblocks;
+    const int tid = threadIdx.x;
+    const int per = (nblocks + RS_THREADS - 1) / RS_THREADS;
+    const int lo = min(tid * per, nblocks), hi = min(lo + per, nblocks);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; i++) sum += row[i];
+    uint32_t total;
+    uint32_t run = block_excl_scan_256(sum, tmp, &total);
+    for (int i = lo; i < hi; i++) {
+        uint32_t c = row[i];
+        row[i] = run;
+        run += c;
+    }
+    if (tid == 0) rowTotal[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
+    const uint32_t *__restrict__ keysIn, const uint32_t *__restrict__ valsIn,
+    uint32_t *__restrict__ keysOut, uint32_t *__restrict__ valsOut, int n, int shift,
+    const uint32_t *__restrict__ histScanned, const uint32_t *__restrict__ rowTotal, int nblocks)
+{
+    __shared__ uint32_t cnt[RS_WAVES][256];
+    __shared__ uint32_t digitStart[256];
+    __shared__ uint32_t gbase[256];
+    __shared__ uint32_t tmp[RS_WAVES];
+    __shared__ uint2 stage[RS_TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+    // global base of every digit: exclusive scan of the digit totals
+    const uint32_t digitBase = block_excl_scan_256(rowTotal[tid], tmp, nullptr);
+    const uint32_t myTileBase = histScanned[(size_t)tid * nblocks + blockIdx.x];
+
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+    const long tile0 = (long)blockIdx.x * RS_TILE;
+    const long wbase = tile0 + (long)w * (RS_ITEMS * 64);
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        long i = wbase + k * 64 + lane;
+        bool valid = i < n;
+        key[k] = valid ? keysIn[i] : 0xffffffffu;
+        val[k] = valid ? (valsIn ? valsIn[i] : (uint32_t)i) : 0u;
+    }
+    __syncthreads(); // counters zeroed
+
+    // stable rank inside the wave: lanes holding the same digit find each other with 8 ballots
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const bool valid = (wbase + k * 64 + lane) < n;
+        const uint32_t d = valid ? ((key[k] >> shift) & 255u) : 255u;
+        unsigned long long peers = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t before = cnt[w][d];
+        const int r = mbcnt64(peers);
+        __builtin_amdgcn_wave_barrier();
+        if (r == 0) cnt[w][d] = before + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        rank[k] = before + (uint32_t)r;
+    }
+    __syncthreads();
+
+    // thread = digit: prefix over the 4 waves, tile total, tile-local start, global base
+    uint32_t tileCount = 0;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; i++) {
+        uint32_t c = cnt[i][tid];
+        cnt[i][tid] = tileCount;
+        tileCount += c;
+    }
+    const uint32_t dstart = block_excl_scan_256(tileCount, tmp, nullptr);
+    digitStart[tid] = dstart;
+    gbase[tid] = digitBase + myTileBase;
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const bool valid = (wbase + k * 64 + lane) < n;
+        const uint32_t d = valid ? ((key[k] >> shift) & 255u) : 255u;
+        const uint32_t lp = digitStart[d] + cnt[w][d] + rank[k];
+        stage[lp] = make_uint2(key[k], val[k]);
+    }
+    __syncthreads();
+
+    const long remain = (long)n - tile0;
+    const int nvalid = remain < RS_TILE ? (int)remain : RS_TILE;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const int s = k * RS_THREADS + tid;
+        if (s < nvalid) {
+            const uint2 kv = stage[s];
+            const uint32_t d = (kv.x >> shift) & 255u;
+            const uint32_t gi = gbase[d] + ((uint32_t)s - digitStart[d]);
+            keysOut[gi] = kv.x;
+            valsOut[gi] = kv.y;
+        }
+    }
+}
+
+// ClearTable + MapTable (FluidSolver.compute:85-112): the table is zeroed with a memset node,
+// then every run of equal keys writes its (start, end).
+__global__ void k_map_table(const uint32_t *__restrict__ skeys, int n, int2 *__restrict__ table)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t k = skeys[s];
+    if (s == 0 || k != skeys[s - 1]) table[k].x = s;
+    if (s == n - 1 || k != skeys[s + 1]) table[k].y = s + 1;
+}

@@ -1,0 +1,387 @@
+// sph_stream.h -- the HBM-streaming kernels: pack/unpack at the ABI, cell keys, bounds,
+// reorder into sorted SoA, ApplyForce + integration + collider response, rigid bodies.
+#pragma once
+#include "sph_device.h"
+
+// ---- ABI packing ------------------------------------------------------------------------------
+// host layout (tightly packed float3 / SphParticle arrays, FluidSPHByGPUSystem.cs:164-181) ->
+// device SoA in ECS order
+__global__ void k_pack_fluid(const float *__restrict__ pos3, const float *__restrict__ vel3,
+                             const uint32_t *__restrict__ matIn, const Mat *__restrict__ mats,
+                             int n, float4 *__restrict__ posm, float4 *__restrict__ velq,
+                             uint32_t *__restrict__ mat, uint32_t *__restrict__ oid)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t m = matIn[i];
+    posm[i] = make_float4(pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2], mats[m].mass);
+    velq[i] = make_float4(vel3[3 * i], vel3[3 * i + 1], vel3[3 * i + 2], 0.f);
+    mat[i] = m;
+    oid[i] = (uint32_t)i;
+}
+
+__global__ void k_pack_boundary(const float *__restrict__ pos3, const float *__restrict__ bparams,
+                                int n, float4 *__restrict__ bposm)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // BoundaryParticleComponent: radius, mass, restDensity (only mass enters the force, :184-189)
+    bposm[i] = make_float4(pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2], bparams[3 * i + 1]);
+}
+
+// sorted slot -> ECS order, float3-packed (for sph_download / sph_read)
+__global__ void k_unpack3(const float4 *__restrict__ src, const uint32_t *__restrict__ oid, int n,
+                          float *__restrict__ out3)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float4 v = src[s];
+    const size_t o = 3 * (size_t)oid[s];
+    out3[o] = v.x;
+    out3[o + 1] = v.y;
+    out3[o + 2] = v.z;
+}
+template <typename T>
+__global__ void k_unpack1(const T *__restrict__ src, const uint32_t *__restrict__ oid, int n,
+                          T *__restrict__ out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    out[oid[s]] = src[s];
+}
+
+// ---- HashPosition (FluidSolver.compute:28-45; CPU: FluidSPHUtils.cs:69,236-261) --------------
+// dense key for the sort; with HASH also the reference's FNV-1 hash and quantised cell (parity
+// outputs, written in ECS order through oid; oid == nullptr means identity).
+template <bool HASH>
+__global__ void k_keys(const float4 *__restrict__ posm, const uint32_t *__restrict__ oid, int n,
+                       GridDesc g, uint32_t *__restrict__ keys, uint32_t *__restrict__ hashes,
+                       int *__restrict__ cells, uint32_t *__restrict__ keysEcs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = posm[i];
+    const int cx = quantize1(p.x, g.cellSize), cy = quantize1(p.y, g.cellSize),
+              cz = quantize1(p.z, g.cellSize);
+    const uint32_t k = dense_key(cx, cy, cz, g);
+    keys[i] = k;
+    if (HASH) {
+        const size_t o = oid ? oid[i] : (uint32_t)i;
+        hashes[o] = fnv1_cell(cx, cy, cz);
+        cells[3 * o] = cx;
+        cells[3 * o + 1] = cy;
+        cells[3 * o + 2] = cz;
+        keysEcs[o] = k;
+    }
+}
+
+// ---- FindBoundsJob min/max (FluidSPHUtils.cs:59-80) -------------------------------------------
+// two-level reduction; partial[6*block + {0..2}] = min xyz, {3..5} = max xyz
+__global__ __launch_bounds__(256) void k_bounds_partial(const float4 *__restrict__ p, int n,
+                                                        float *__restrict__ partial)
+{
+    __shared__ float sm[6][4];
+    float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 v = p[i];
+        mn[0] = fminf(mn[0], v.x); mn[1] = fminf(mn[1], v.y); mn[2] = fminf(mn[2], v.z);
+        mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], d, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, 64));
+        }
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0)
+        for (int a = 0; a < 3; a++) {
+            sm[a][w] = mn[a];
+            sm[3 + a][w] = mx[a];
+        }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sm[threadIdx.x][0];
+        for (int i = 1; i < 4; i++)
+            v = threadIdx.x < 3 ? fminf(v, sm[threadIdx.x][i]) : fmaxf(v, sm[threadIdx.x][i]);
+        partial[6 * blockIdx.x + threadIdx.x] = v;
+    }
+}
+
+// ---- reorder: gather the state into the new sorted order --------------------------------------
+// perm[s] = index in the current arrays of the particle that belongs in sorted slot s (stable in
+// the CURRENT order).  Ties inside a cell are re-ranked by ECS id so that the resident order is
+// always exactly "stable by (cell key, particle id)" whatever the previous order was.
+__global__ __launch_bounds__(256) void k_reorder(
+    const uint32_t *__restrict__ perm, const uint32_t *__restrict__ skeys,
+    const int2 *__restrict__ table, int n, const float4 *__restrict__ posmIn,
+    const float4 *__restrict__ velqIn, const uint32_t *__restrict__ matIn,
+    const uint32_t *__restrict__ oidIn, float4 *__restrict__ posmOut,
+    float4 *__restrict__ velqOut, uint32_t *__restrict__ matOut, uint32_t *__restrict__ oidOut)
+{
+    __shared__ uint32_t ids[256];
+    const int blockBase = blockIdx.x * 256;
+    const int s = blockBase + threadIdx.x;
+    uint32_t c = 0, id = 0;
+    if (s < n) {
+        c = perm[s];
+        id = oidIn[c];
+    }
+    ids[threadIdx.x] = id;
+    __syncthreads();
+    if (s >= n) return;
+    const int2 cell = table[skeys[s]];
+    int rank = 0;
+    for (int t = cell.x; t < cell.y; t++) {
+        if (t == s) continue;
+        const int rel = t - blockBase;
+        const uint32_t idt = (rel >= 0 && rel < 256) ? ids[rel] : oidIn[perm[t]];
+        rank += idt < id;
+    }
+    const int dst = cell.x + rank;
+    posmOut[dst] = posmIn[c];
+    velqOut[dst] = velqIn[c];
+    matOut[dst] = matIn[c];
+    oidOut[dst] = id;
+}
+
+// boundary: plain gather (the input order is the id order, so the stable sort needs no re-rank)
+__global__ void k_gather4(const uint32_t *__restrict__ perm, int n,
+                          const float4 *__restrict__ in, float4 *__restrict__ out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) out[s] = in[perm[s]];
+}
+
+// ---- ApplyForceJob (FluidSPHUtils.cs:105-124) + row I (integration, colliders) ----------------
+__device__ __forceinline__ float dot3f(const float *a, const float *b)
+{
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+
+template <bool APPLY, bool INTEGRATE>
+__global__ __launch_bounds__(256) void k_apply_integrate(
+    float4 *__restrict__ posm, float4 *__restrict__ velq, const float4 *__restrict__ force,
+    const float *__restrict__ rho, const uint32_t *__restrict__ mat,
+    const Mat *__restrict__ mats, int n, float dt, const DevBox *__restrict__ boxes, int nboxes,
+    float particleRestitution, float *__restrict__ bodyImpulse)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), vv = pv;
+    Mat m = mats[0];
+    if (live) {
+        pv = posm[i];
+        vv = velq[i];
+        m = mats[mat[i]];
+    }
+    float x[3] = {pv.x, pv.y, pv.z}, v[3] = {vv.x, vv.y, vv.z};
+    if (APPLY && live) {
+        const float d = rho[i];
+        if (d != 0.f) {
+            const float4 f = force[i];
+            const float ff[3] = {f.x, f.y, f.z};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                // velocity.ApplyLinearImpulse(mass, F / rho / invM * dt): Linear += impulse * invM
+                const float impulse = ff[a] / d / m.invMass * dt;
+                v[a] += impulse * m.invMass;
+            }
+        }
+    }
+    if (INTEGRATE) {
+        const float r = m.radius;
+#pragma unroll
+        for (int a = 0; a < 3; a++) x[a] = x[a] + v[a] * dt;
+        for (int k = 0; k < nboxes; k++) {
+            const DevBox &bx = boxes[k];
+            float imp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            bool pushed = false;
+            if (live) {
+                const float d[3] = {x[0] - bx.c[0], x[1] - bx.c[1], x[2] - bx.c[2]};
+                float p[3], delta[3], nl[3] = {0.f, 0.f, 0.f}, pen = 0.f;
+                p[0] = (bx.R[0] * d[0] + bx.R[3] * d[1]) + bx.R[6] * d[2];
+                p[1] = (bx.R[1] * d[0] + bx.R[4] * d[1]) + bx.R[7] * d[2];
+                p[2] = (bx.R[2] * d[0] + bx.R[5] * d[1]) + bx.R[8] * d[2];
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+                    delta[a] = p[a] - fminf(fmaxf(p[a], -bx.he[a]), bx.he[a]);
+                const float dist2 = dot3f(delta, delta);
+                bool contact = false;
+                if (dist2 > 0.f) {
+                    if (dist2 < r * r) {
+                        const float dist = sqrtf(dist2);
+#pragma unroll
+                        for (int a = 0; a < 3; a++) nl[a] = delta[a] / dist;
+                        pen = r - dist;
+                        contact = true;
+                    }
+                } else {
+                    int best = 0;
+                    float bestd = bx.he[0] - fabsf(p[0]);
+#pragma unroll
+                    for (int a = 1; a < 3; a++) {
+                        const float da = bx.he[a] - fabsf(p[a]);
+                        if (da < bestd) { bestd = da; best = a; }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+                        if (a == best) nl[a] = p[a] < 0.f ? -1.f : 1.f;
+                    pen = bestd + r;
+                    contact = true;
+                }
+                if (contact) {
+                    float nw[3];
+                    nw[0] = (bx.R[0] * nl[0] + bx.R[1] * nl[1]) + bx.R[2] * nl[2];
+                    nw[1] = (bx.R[3] * nl[0] + bx.R[4] * nl[1]) + bx.R[5] * nl[2];
+                    nw[2] = (bx.R[6] * nl[0] + bx.R[7] * nl[1]) + bx.R[8] * nl[2];
+                    float rc[3], vb[3], vrel[3];
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        x[a] = x[a] + nw[a] * pen;
+                        rc[a] = (x[a] - nw[a] * r) - bx.c[a];
+                    }
+                    vb[0] = bx.av[1] * rc[2] - bx.av[2] * rc[1];
+                    vb[1] = bx.av[2] * rc[0] - bx.av[0] * rc[2];
+                    vb[2] = bx.av[0] * rc[1] - bx.av[1] * rc[0];
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        vb[a] = bx.lv[a] + vb[a];
+                        vrel[a] = v[a] - vb[a];
+                    }
+                    const float vn = dot3f(vrel, nw);
+                    if (vn < 0.f) {
+                        const float e = fmaxf(particleRestitution, bx.restitution);
+                        if (!bx.dynamic) {
+                            const float sc = (1.f + e) * vn;
+#pragma unroll
+                            for (int a = 0; a < 3; a++) v[a] = v[a] - sc * nw[a];
+                        } else {
+                            float rxn[3], loc[3], w[3];
+                            rxn[0] = rc[1] * nw[2] - rc[2] * nw[1];
+                            rxn[1] = rc[2] * nw[0] - rc[0] * nw[2];
+                            rxn[2] = rc[0] * nw[1] - rc[1] * nw[0];
+                            loc[0] = ((bx.R[0] * rxn[0] + bx.R[3] * rxn[1]) + bx.R[6] * rxn[2]) * bx.invI[0];
+                            loc[1] = ((bx.R[1] * rxn[0] + bx.R[4] * rxn[1]) + bx.R[7] * rxn[2]) * bx.invI[1];
+                            loc[2] = ((bx.R[2] * rxn[0] + bx.R[5] * rxn[1]) + bx.R[8] * rxn[2]) * bx.invI[2];
+                            w[0] = (bx.R[0] * loc[0] + bx.R[1] * loc[1]) + bx.R[2] * loc[2];
+                            w[1] = (bx.R[3] * loc[0] + bx.R[4] * loc[1]) + bx.R[5] * loc[2];
+                            w[2] = (bx.R[6] * loc[0] + bx.R[7] * loc[1]) + bx.R[8] * loc[2];
+                            const float denom = (m.invMass + bx.invMass) + dot3f(rxn, w);
+                            const float j = -((1.f + e) * vn) / denom;
+                            const float jp = j * m.invMass;
+#pragma unroll
+                            for (int a = 0; a < 3; a++) {
+                                v[a] = v[a] + jp * nw[a];
+                                imp[a] = -(j * nw[a]);
+                                imp[3 + a] = -(j * rxn[a]);
+                            }
+                            pushed = true;
+                        }
+                    }
+                }
+            }
+            // reaction on the rigid body: wave-level sum, one atomic per wave and component
+            if (bx.dynamic && __any(pushed)) {
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+                    float t = imp[a];
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+                    if (lane_id() == 0) atomicAdd(&bodyImpulse[6 * k + a], t);
+                }
+            }
+        }
+    }
+    if (live) {
+        if (INTEGRATE) posm[i] = make_float4(x[0], x[1], x[2], pv.w);
+        velq[i] = make_float4(v[0], v[1], v[2], vv.w);
+    }
+}
+
+// ---- rigid bodies: one thread per box (K is small) --------------------------------------------
+// state: SphBox as 25 floats (include/sphfluid.h).  integrate != 0: apply impulses, gravity,
+// damping, integrate the pose; always: refresh the DevBox view, zero impulses.
+__device__ __forceinline__ void quat_to_mat(const float *q, float *m)
+{
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    m[0] = 1.f - 2.f * (y * y + z * z); m[1] = 2.f * (x * y - z * w); m[2] = 2.f * (x * z + y * w);
+    m[3] = 2.f * (x * y + z * w); m[4] = 1.f - 2.f * (x * x + z * z); m[5] = 2.f * (y * z - x * w);
+    m[6] = 2.f * (x * z - y * w); m[7] = 2.f * (y * z + x * w); m[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+__global__ void k_bodies(float *__restrict__ state, DevBox *__restrict__ dev,
+                         float *__restrict__ bodyImpulse, int nboxes, int integrate, float dt,
+                         float gx, float gy, float gz, int bounded, float bminx, float bminy,
+                         float bminz, float bmaxx, float bmaxy, float bmaxz)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nboxes) return;
+    float *b = state + 25 * k;
+    float *center = b, *rot = b + 3, *he = b + 7, *lv = b + 10, *av = b + 13, *invI = b + 17;
+    const float invMass = b[16], linD = b[22], angD = b[23], gfac = b[24];
+    const bool dynamic = invMass != 0.f || invI[0] != 0.f || invI[1] != 0.f || invI[2] != 0.f;
+    float m[9];
+    quat_to_mat(rot, m);
+    if (integrate && dynamic) {
+        const float *imp = bodyImpulse + 6 * k;
+        const float g[3] = {gx, gy, gz}, bmin[3] = {bminx, bminy, bminz},
+                    bmax[3] = {bmaxx, bmaxy, bmaxz};
+        float loc[3], dw[3];
+        loc[0] = ((m[0] * imp[3] + m[3] * imp[4]) + m[6] * imp[5]) * invI[0];
+        loc[1] = ((m[1] * imp[3] + m[4] * imp[4]) + m[7] * imp[5]) * invI[1];
+        loc[2] = ((m[2] * imp[3] + m[5] * imp[4]) + m[8] * imp[5]) * invI[2];
+        dw[0] = (m[0] * loc[0] + m[1] * loc[1]) + m[2] * loc[2];
+        dw[1] = (m[3] * loc[0] + m[4] * loc[1]) + m[5] * loc[2];
+        dw[2] = (m[6] * loc[0] + m[7] * loc[1]) + m[8] * loc[2];
+        const float ld = fminf(fmaxf(1.f - linD * dt, 0.f), 1.f);
+        const float ad = fminf(fmaxf(1.f - angD * dt, 0.f), 1.f);
+        for (int a = 0; a < 3; a++) {
+            lv[a] = (lv[a] + imp[a] * invMass + g[a] * gfac * dt) * ld;
+            av[a] = (av[a] + dw[a]) * ad;
+            center[a] = center[a] + lv[a] * dt;
+        }
+        const float hd = 0.5f * dt;
+        const float q0 = rot[0], q1 = rot[1], q2 = rot[2], q3 = rot[3];
+        float nq[4];
+        nq[0] = q0 + hd * ((av[0] * q3 + av[1] * q2) - av[2] * q1);
+        nq[1] = q1 + hd * ((av[1] * q3 + av[2] * q0) - av[0] * q2);
+        nq[2] = q2 + hd * ((av[2] * q3 + av[0] * q1) - av[1] * q0);
+        nq[3] = q3 + hd * -((av[0] * q0 + av[1] * q1) + av[2] * q2);
+        float len2 = 0.f;
+        for (int a = 0; a < 4; a++) len2 += nq[a] * nq[a];
+        const float il = 1.f / sqrtf(len2);
+        for (int a = 0; a < 4; a++) rot[a] = nq[a] * il;
+        quat_to_mat(rot, m);
+        if (bounded) {
+            for (int a = 0; a < 3; a++) {
+                const float ext = (fabsf(m[3 * a]) * he[0] + fabsf(m[3 * a + 1]) * he[1]) +
+                                  fabsf(m[3 * a + 2]) * he[2];
+                if (center[a] - ext < bmin[a]) {
+                    center[a] = bmin[a] + ext;
+                    if (lv[a] < 0.f) lv[a] = 0.f;
+                }
+                if (center[a] + ext > bmax[a]) {
+                    center[a] = bmax[a] - ext;
+                    if (lv[a] > 0.f) lv[a] = 0.f;
+                }
+            }
+        }
+    }
+    DevBox d;
+    for (int a = 0; a < 3; a++) {
+        d.c[a] = center[a];
+        d.he[a] = he[a];
+        d.lv[a] = lv[a];
+        d.av[a] = av[a];
+        d.invI[a] = invI[a];
+    }
+    for (int a = 0; a < 9; a++) d.R[a] = m[a];
+    d.invMass = invMass;
+    d.restitution = b[20];
+    d.dynamic = dynamic ? 1 : 0;
+    dev[k] = d;
+    for (int a = 0; a < 6; a++) bodyImpulse[6 * k + a] = 0.f;
+}

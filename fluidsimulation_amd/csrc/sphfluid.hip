@@ -1,0 +1,1176 @@
+// sphfluid.hip -- libsphfluid.so: host side of the C ABI in include/sphfluid.h.
+//
+// Owns the device memory, the stream and the per-frame sequence; the kernels live in
+// sph_sort.h / sph_neighbors.h / sph_stream.h.  gfx950 only; there is no CPU path.
+#include "../../include/sphfluid.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "sph_device.h"
+#include "sph_neighbors.h"
+#include "sph_sort.h"
+#include "sph_stream.h"
+
+static_assert(sizeof(SphParticle) == 16, "FluidParticleComponent layout");
+static_assert(sizeof(SphBoundaryParticle) == 12, "BoundaryParticleComponent layout");
+static_assert(sizeof(SphBox) == 25 * 4, "SphBox layout");
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair {
+    hipEvent_t a, b;
+    int stage;
+};
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0; // elements
+};
+
+struct MatKey {
+    uint32_t w[5];
+    bool operator==(const MatKey &o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }
+};
+struct MatKeyHash {
+    size_t operator()(const MatKey &k) const
+    {
+        uint64_t h = 1469598103934665603ull;
+        for (int i = 0; i < 5; i++) h = (h ^ k.w[i]) * 1099511628211ull;
+        return (size_t)h;
+    }
+};
+
+} // namespace
+
+struct SphCtx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    std::string err;
+    int debug = 0;
+    int maxCells = 1 << 25;
+
+    // fluid
+    int n = 0;
+    int cur = 0; // which of the double buffers holds the current state
+    DevBuf<float4> posm[2], velq[2];
+    DevBuf<uint32_t> mat[2], oid[2];
+    DevBuf<uint32_t> keysA, keysB, valsA, valsB;
+    DevBuf<float> rho, prs;
+    DevBuf<float4> force;
+    DevBuf<int> dcount, fcount;
+    DevBuf<uint32_t> hashes, keysEcs;
+    DevBuf<int> cells;
+    DevBuf<float> io3a, io3b, io1;
+    DevBuf<uint32_t> ioU;
+    uint32_t *sortedKeys = nullptr; // points into keysA/keysB
+    uint32_t *sortedVals = nullptr;
+    bool haveKeys = false, haveSort = false, haveTable = false, ordered = false;
+    bool haveDensity = false, haveForce = false;
+
+    // materials
+    std::vector<MatKey> matKeys;
+    std::vector<Mat> mats;
+    float matRate = 0.f;
+    DevBuf<Mat> dmats;
+    std::unordered_map<MatKey, uint32_t, MatKeyHash> matIndex;
+    std::vector<uint32_t> hostMatIdx;
+
+    // grid
+    GridDesc grid{};
+    bool gridExplicit = false, gridValid = false;
+    DevBuf<int2> table, btable;
+
+    // boundary
+    int nb = 0;
+    DevBuf<float> bpos3, bpar3;
+    DevBuf<float4> bposmIn, bposm;
+    DevBuf<uint32_t> bkeysA, bkeysB, bvalsA, bvalsB;
+    uint32_t *bperm = nullptr;
+    bool boundaryDirty = true;
+    float hostBMin[3] = {0, 0, 0}, hostBMax[3] = {0, 0, 0};
+
+    // colliders
+    int nboxes = 0;
+    DevBuf<float> boxState;
+    DevBuf<DevBox> devBoxes;
+    DevBuf<float> bodyImpulse;
+
+    // sort scratch
+    DevBuf<uint32_t> hist, rowTotal;
+    DevBuf<float> partial;
+
+    // timings
+    bool timing = false;
+    std::vector<hipEvent_t> freeEvents;
+    std::vector<EventPair> pending;
+    SphTimings tm{};
+};
+
+namespace {
+
+int fail(SphCtx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(c, e_ == hipErrorOutOfMemory ? SPH_E_NOMEM : SPH_E_DEVICE, "%s: %s",     \
+                        #expr, hipGetErrorString(e_));                                           \
+    } while (0)
+
+template <typename T> int ensure(SphCtx *c, DevBuf<T> &b, size_t count, bool grow = true)
+{
+    if (count <= b.cap && b.p) return SPH_OK;
+    size_t want = grow ? std::max(count, b.cap + b.cap / 2) : count;
+    if (want == 0) want = 1;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    HIPCHK(c, hipMalloc((void **)&b.p, want * sizeof(T)));
+    b.cap = want;
+    return SPH_OK;
+}
+template <typename T> void release(DevBuf<T> &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+inline int blocks_for(long n, int per) { return (int)((n + per - 1) / per); }
+
+struct StageTimer {
+    SphCtx *c;
+    EventPair ep;
+    bool on;
+    StageTimer(SphCtx *ctx, int stage) : c(ctx), on(ctx->timing)
+    {
+        if (!on) return;
+        for (hipEvent_t *e : {&ep.a, &ep.b}) {
+            if (!c->freeEvents.empty()) {
+                *e = c->freeEvents.back();
+                c->freeEvents.pop_back();
+            } else if (hipEventCreate(e) != hipSuccess) {
+                on = false;
+                return;
+            }
+        }
+        ep.stage = stage;
+        (void)hipEventRecord(ep.a, c->stream);
+    }
+    ~StageTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(ep.b, c->stream);
+        c->pending.push_back(ep);
+    }
+};
+
+int collect_timings(SphCtx *c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (const EventPair &ep : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+            c->tm.ms[ep.stage] += ms;
+            c->tm.launches[ep.stage] += 1;
+        }
+        c->freeEvents.push_back(ep.a);
+        c->freeEvents.push_back(ep.b);
+    }
+    c->pending.clear();
+    return SPH_OK;
+}
+
+// ---- materials ----------------------------------------------------------------------------
+// constants in float32, in the reference's evaluation order (FluidSPHByCPUSystem.cs:53-60,
+// 133-135,224-231); math.PI = 3.14159274f
+Mat make_mat(const MatKey &k, float rate)
+{
+    float radius, restDensity, viscosity, gasConstant, invMass;
+    std::memcpy(&radius, &k.w[0], 4);
+    std::memcpy(&restDensity, &k.w[1], 4);
+    std::memcpy(&viscosity, &k.w[2], 4);
+    std::memcpy(&gasConstant, &k.w[3], 4);
+    std::memcpy(&invMass, &k.w[4], 4);
+    const float PI = 3.14159274f;
+    Mat m{};
+    m.radius = radius;
+    m.restDensity = restDensity;
+    m.viscosity = viscosity;
+    m.gasConstant = gasConstant;
+    m.invMass = invMass;
+    m.mass = 1.0f / invMass;
+    m.h = radius * rate;
+    m.h2 = m.h * m.h;
+    volatile float h9 = powf(m.h, 9.0f);
+    volatile float den = 64.0f * PI * h9;
+    m.poly6 = m.mass * 315.0f / den;
+    volatile float h6 = powf(m.h, 6.0f);
+    volatile float den6 = PI * h6;
+    m.spiky = 45.0f / den6;
+    // least t with sqrtf(t) >= h  (sqrtf is correctly rounded and monotone)
+    float t = m.h2;
+    for (int i = 0; i < 8 && t > 0.f && sqrtf(nextafterf(t, 0.f)) >= m.h; i++) t = nextafterf(t, 0.f);
+    for (int i = 0; i < 8 && sqrtf(t) < m.h; i++) t = nextafterf(t, INFINITY);
+    m.thrF = t;
+    return m;
+}
+
+int upload_mats(SphCtx *c, float rate)
+{
+    c->mats.resize(c->matKeys.size());
+    for (size_t i = 0; i < c->matKeys.size(); i++) c->mats[i] = make_mat(c->matKeys[i], rate);
+    c->matRate = rate;
+    int rc = ensure(c, c->dmats, std::max<size_t>(c->mats.size(), 1));
+    if (rc) return rc;
+    if (!c->mats.empty())
+        HIPCHK(c, hipMemcpyAsync(c->dmats.p, c->mats.data(), c->mats.size() * sizeof(Mat),
+                                 hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+// deduplicate (params, invMass) tuples into the material table; fills c->hostMatIdx
+void build_materials(SphCtx *c, const float *invMass, const SphParticle *params, int n)
+{
+    c->matKeys.clear();
+    c->matIndex.clear();
+    c->hostMatIdx.resize((size_t)n);
+    MatKey last{};
+    uint32_t lastIdx = 0;
+    bool haveLast = false;
+    for (int i = 0; i < n; i++) {
+        MatKey k;
+        std::memcpy(&k.w[0], &params[i], 16);
+        std::memcpy(&k.w[4], &invMass[i], 4);
+        if (haveLast && k == last) {
+            c->hostMatIdx[i] = lastIdx;
+            continue;
+        }
+        auto it = c->matIndex.find(k);
+        uint32_t idx;
+        if (it == c->matIndex.end()) {
+            idx = (uint32_t)c->matKeys.size();
+            c->matKeys.push_back(k);
+            c->matIndex.emplace(k, idx);
+        } else {
+            idx = it->second;
+        }
+        c->hostMatIdx[i] = idx;
+        last = k;
+        lastIdx = idx;
+        haveLast = true;
+    }
+}
+
+// ---- grid ---------------------------------------------------------------------------------
+int key_bits(int cells)
+{
+    int b = 1;
+    while ((1ll << b) < cells) b++;
+    return b;
+}
+
+void set_grid(SphCtx *c, const int origin[3], const int dims[3], float cellSize)
+{
+    GridDesc g;
+    g.ox = origin[0]; g.oy = origin[1]; g.oz = origin[2];
+    g.gx = dims[0]; g.gy = dims[1]; g.gz = dims[2];
+    g.cellSize = cellSize;
+    g.cells = dims[0] * dims[1] * dims[2];
+    const GridDesc &o = c->grid;
+    if (!c->gridValid || o.ox != g.ox || o.oy != g.oy || o.oz != g.oz || o.gx != g.gx ||
+        o.gy != g.gy || o.gz != g.gz || o.cellSize != g.cellSize)
+        c->boundaryDirty = true;
+    c->grid = g;
+    c->gridValid = true;
+}
+
+int bounds_of(SphCtx *c, const float4 *p, int n, float mn[3], float mx[3])
+{
+    const int nb = std::max(1, std::min(1024, blocks_for(n, 256)));
+    int rc = ensure(c, c->partial, (size_t)6 * 1024, false);
+    if (rc) return rc;
+    k_bounds_partial<<<nb, 256, 0, c->stream>>>(p, n, c->partial.p);
+    std::vector<float> h((size_t)6 * nb);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->partial.p, h.size() * 4, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int a = 0; a < 3; a++) {
+        mn[a] = 3.402823466e+38f;
+        mx[a] = -3.402823466e+38f;
+    }
+    for (int b = 0; b < nb; b++)
+        for (int a = 0; a < 3; a++) {
+            mn[a] = std::min(mn[a], h[6 * b + a]);
+            mx[a] = std::max(mx[a], h[6 * b + 3 + a]);
+        }
+    return SPH_OK;
+}
+
+// size the periodic table from the bounds of fluid + boundary, with a margin of two cells; when
+// the box would exceed maxCells the longest axes are cut (cells then alias, which is harmless:
+// aliased candidates fail the distance test exactly as hash collisions do in the reference)
+int auto_grid(SphCtx *c, float cellSize)
+{
+    float mn[3], mx[3];
+    int rc = bounds_of(c, c->posm[c->cur].p, c->n, mn, mx);
+    if (rc) return rc;
+    if (c->nb > 0)
+        for (int a = 0; a < 3; a++) {
+            mn[a] = std::min(mn[a], c->hostBMin[a]);
+            mx[a] = std::max(mx[a], c->hostBMax[a]);
+        }
+    int lo[3], hi[3], dims[3], origin[3];
+    for (int a = 0; a < 3; a++) {
+        if (!(mn[a] <= mx[a]) || !std::isfinite(mn[a]) || !std::isfinite(mx[a])) {
+            mn[a] = 0.f;
+            mx[a] = 0.f;
+        }
+        double l = std::floor((double)mn[a] / cellSize), h = std::floor((double)mx[a] / cellSize);
+        l = std::max(l, -1.0e9);
+        h = std::min(h, 1.0e9);
+        lo[a] = (int)l;
+        hi[a] = (int)h;
+    }
+    if (c->gridValid && !c->gridExplicit && c->grid.cellSize == cellSize) {
+        // keep the current table while the particles still fit inside it
+        const GridDesc &g = c->grid;
+        const int o[3] = {g.ox, g.oy, g.oz}, d[3] = {g.gx, g.gy, g.gz};
+        bool fits = true;
+        for (int a = 0; a < 3; a++) fits = fits && lo[a] >= o[a] && hi[a] < o[a] + d[a];
+        if (fits) return SPH_OK;
+    }
+    long long prod = 1;
+    for (int a = 0; a < 3; a++) {
+        origin[a] = lo[a] - 2;
+        long long d = (long long)hi[a] - lo[a] + 1 + 4;
+        dims[a] = (int)std::min<long long>(std::max<long long>(d, 4), 1 << 20);
+        prod *= dims[a];
+    }
+    while (prod > c->maxCells) {
+        int a = (dims[0] >= dims[1] && dims[0] >= dims[2]) ? 0 : (dims[1] >= dims[2] ? 1 : 2);
+        if (dims[a] <= 4) break;
+        prod /= dims[a];
+        dims[a] = std::max(4, dims[a] / 2);
+        prod *= dims[a];
+    }
+    set_grid(c, origin, dims, cellSize);
+    return SPH_OK;
+}
+
+// ---- radix sort driver --------------------------------------------------------------------
+// sorts (keysA, implicit index) by the low `bits` bits; result pointers returned
+int radix_sort(SphCtx *c, uint32_t *keysA, uint32_t *valsA, uint32_t *keysB, uint32_t *valsB,
+               int n, int bits, uint32_t **outKeys, uint32_t **outVals)
+{
+    const int nblocks = std::max(1, blocks_for(n, RS_TILE));
+    int rc = ensure(c, c->hist, (size_t)256 * nblocks);
+    if (rc) return rc;
+    rc = ensure(c, c->rowTotal, 256, false);
+    if (rc) return rc;
+    const int passes = std::max(1, (bits + 7) / 8);
+    uint32_t *kin = keysA, *vin = nullptr, *kout = keysB, *vout = valsB;
+    for (int p = 0; p < passes; p++) {
+        const int shift = 8 * p;
+        k_radix_hist<<<nblocks, RS_THREADS, 0, c->stream>>>(kin, n, shift, c->hist.p, nblocks);
+        k_radix_scan<<<256, RS_THREADS, 0, c->stream>>>(c->hist.p, c->rowTotal.p, nblocks);
+        k_radix_scatter<<<nblocks, RS_THREADS, 0, c->stream>>>(kin, vin, kout, vout, n, shift,
+                                                                c->hist.p, c->rowTotal.p,
+                                                                nblocks);
+        if (p == 0) {
+            kin = keysB; vin = valsB; kout = keysA; vout = valsA;
+        } else {
+            std::swap(kin, kout);
+            std::swap(vin, vout);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    *outKeys = kin;
+    *outVals = vin;
+    return SPH_OK;
+}
+
+int ensure_fluid(SphCtx *c, int n)
+{
+    int rc = 0;
+    const size_t N = (size_t)std::max(n, 1);
+    for (int i = 0; i < 2 && !rc; i++) {
+        rc = ensure(c, c->posm[i], N);
+        if (!rc) rc = ensure(c, c->velq[i], N);
+        if (!rc) rc = ensure(c, c->mat[i], N);
+        if (!rc) rc = ensure(c, c->oid[i], N);
+    }
+    if (!rc) rc = ensure(c, c->keysA, N);
+    if (!rc) rc = ensure(c, c->keysB, N);
+    if (!rc) rc = ensure(c, c->valsA, N);
+    if (!rc) rc = ensure(c, c->valsB, N);
+    if (!rc) rc = ensure(c, c->rho, N);
+    if (!rc) rc = ensure(c, c->prs, N);
+    if (!rc) rc = ensure(c, c->force, N);
+    return rc;
+}
+
+int ensure_debug(SphCtx *c)
+{
+    int rc = 0;
+    const size_t N = (size_t)std::max(c->n, 1);
+    if (c->debug & SPH_DEBUG_HASHES) {
+        rc = ensure(c, c->hashes, N);
+        if (!rc) rc = ensure(c, c->keysEcs, N);
+        if (!rc) rc = ensure(c, c->cells, 3 * N);
+    }
+    if (!rc && (c->debug & SPH_DEBUG_COUNTS)) {
+        rc = ensure(c, c->dcount, N);
+        if (!rc) rc = ensure(c, c->fcount, N);
+    }
+    return rc;
+}
+
+// boundary: keys -> sort -> table -> gather, once per (grid, boundary) change
+int prepare_boundary(SphCtx *c)
+{
+    if (!c->boundaryDirty) return SPH_OK;
+    int rc = ensure(c, c->btable, (size_t)c->grid.cells);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->btable.p, 0, (size_t)c->grid.cells * sizeof(int2), c->stream));
+    if (c->nb > 0) {
+        const int B = c->nb;
+        rc = ensure(c, c->bposm, (size_t)B);
+        if (!rc) rc = ensure(c, c->bkeysA, (size_t)B);
+        if (!rc) rc = ensure(c, c->bkeysB, (size_t)B);
+        if (!rc) rc = ensure(c, c->bvalsA, (size_t)B);
+        if (!rc) rc = ensure(c, c->bvalsB, (size_t)B);
+        if (rc) return rc;
+        k_keys<false><<<blocks_for(B, 256), 256, 0, c->stream>>>(
+            c->bposmIn.p, nullptr, B, c->grid, c->bkeysA.p, nullptr, nullptr, nullptr);
+        uint32_t *sk, *sv;
+        rc = radix_sort(c, c->bkeysA.p, c->bvalsA.p, c->bkeysB.p, c->bvalsB.p, B,
+                        key_bits(c->grid.cells), &sk, &sv);
+        if (rc) return rc;
+        k_map_table<<<blocks_for(B, 256), 256, 0, c->stream>>>(sk, B, c->btable.p);
+        k_gather4<<<blocks_for(B, 256), 256, 0, c->stream>>>(sv, B, c->bposmIn.p, c->bposm.p);
+        c->bperm = sv;
+        HIPCHK(c, hipGetLastError());
+    }
+    c->boundaryDirty = false;
+    return SPH_OK;
+}
+
+int check_params(SphCtx *c, const SphParams *p)
+{
+    if (!c) return SPH_E_INVALID;
+    if (!p) return fail(c, SPH_E_INVALID, "params is NULL");
+    if (!(p->gridSize > 0.f) || !std::isfinite(p->gridSize))
+        return fail(c, SPH_E_INVALID, "gridSize must be positive and finite");
+    if (!(p->kernelRadiusRate > 0.f)) return fail(c, SPH_E_INVALID, "kernelRadiusRate must be > 0");
+    return SPH_OK;
+}
+
+// (re)derive everything that depends on the per-step scalars
+int sync_params(SphCtx *c, const SphParams *p)
+{
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (c->n <= 0) return fail(c, SPH_E_INVALID, "no particles uploaded");
+    if (c->matRate != p->kernelRadiusRate) {
+        rc = upload_mats(c, p->kernelRadiusRate);
+        if (rc) return rc;
+    }
+    if (!c->gridValid || c->grid.cellSize != p->gridSize) {
+        if (c->gridExplicit) {
+            const int o[3] = {c->grid.ox, c->grid.oy, c->grid.oz};
+            const int d[3] = {c->grid.gx, c->grid.gy, c->grid.gz};
+            set_grid(c, o, d, p->gridSize);
+        } else {
+            rc = auto_grid(c, p->gridSize);
+            if (rc) return rc;
+        }
+        c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
+    }
+    return SPH_OK;
+}
+
+} // namespace
+
+// =============================================================================================
+extern "C" {
+
+int sph_create(const SphConfig *cfg, SphCtx **out)
+{
+    if (!out) return fail(nullptr, SPH_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, SPH_E_NODEVICE, "no HIP device visible (libsphfluid has no CPU path)");
+    const int dev = cfg ? cfg->device : 0;
+    if (dev < 0 || dev >= ndev)
+        return fail(nullptr, SPH_E_INVALID, "device %d out of range (%d visible)", dev, ndev);
+    SphCtx *c = new (std::nothrow) SphCtx();
+    if (!c) return fail(nullptr, SPH_E_NOMEM, "host allocation failed");
+    c->device = dev;
+    if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&c->prop, dev) != hipSuccess) {
+        delete c;
+        return fail(nullptr, SPH_E_DEVICE, "cannot open device %d", dev);
+    }
+    if (std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string arch = c->prop.gcnArchName;
+        delete c;
+        return fail(nullptr, SPH_E_NODEVICE, "device %d is %s; this library is built for gfx950 only",
+                    dev, arch.c_str());
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(nullptr, SPH_E_DEVICE, "hipStreamCreate failed");
+    }
+    if (cfg && cfg->maxCells > 0) c->maxCells = std::max(cfg->maxCells, 64);
+    c->timing = cfg && cfg->enableTimings;
+    *out = c;
+    return SPH_OK;
+}
+
+int sph_destroy(SphCtx *c)
+{
+    if (!c) return SPH_E_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 2; i++) {
+        release(c->posm[i]); release(c->velq[i]); release(c->mat[i]); release(c->oid[i]);
+    }
+    release(c->keysA); release(c->keysB); release(c->valsA); release(c->valsB);
+    release(c->rho); release(c->prs); release(c->force); release(c->dcount); release(c->fcount);
+    release(c->hashes); release(c->keysEcs); release(c->cells);
+    release(c->io3a); release(c->io3b); release(c->io1); release(c->ioU);
+    release(c->dmats); release(c->table); release(c->btable);
+    release(c->bpos3); release(c->bpar3); release(c->bposmIn); release(c->bposm);
+    release(c->bkeysA); release(c->bkeysB); release(c->bvalsA); release(c->bvalsB);
+    release(c->boxState); release(c->devBoxes); release(c->bodyImpulse);
+    release(c->hist); release(c->rowTotal); release(c->partial);
+    for (const EventPair &ep : c->pending) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    for (hipEvent_t e : c->freeEvents) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SPH_OK;
+}
+
+const char *sph_last_error(const SphCtx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int sph_device_name(SphCtx *c, char *name, size_t cap, int32_t *cus)
+{
+    if (!c) return SPH_E_INVALID;
+    if (name && cap) snprintf(name, cap, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    if (cus) *cus = c->prop.multiProcessorCount;
+    return SPH_OK;
+}
+
+int sph_set_debug(SphCtx *c, int32_t flags)
+{
+    if (!c) return SPH_E_INVALID;
+    c->debug = flags;
+    return SPH_OK;
+}
+
+int sph_synchronize(SphCtx *c)
+{
+    if (!c) return SPH_E_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+float sph_find_grid_size(const SphParticle *params, const int32_t *chunk_first, int32_t nchunks,
+                         float rate)
+{
+    // FindGridSizeJob.Execute, FluidSPHUtils.cs:35-43, gridSize[0] starts at float.MaxValue
+    float grid = 3.402823466e+38f;
+    for (int c = 0; c < nchunks; c++) {
+        const float radius = params[chunk_first[c]].radius;
+        if (radius < grid / rate) grid = radius * rate;
+    }
+    return grid;
+}
+
+int sph_set_boundary(SphCtx *c, const float *bpos, const SphBoundaryParticle *bparams, int32_t B)
+{
+    if (!c) return SPH_E_INVALID;
+    if (B < 0 || (B > 0 && (!bpos || !bparams))) return fail(c, SPH_E_INVALID, "bad boundary arrays");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->nb = B;
+    c->boundaryDirty = true;
+    if (B == 0) return SPH_OK;
+    int rc = ensure(c, c->bpos3, (size_t)3 * B);
+    if (!rc) rc = ensure(c, c->bpar3, (size_t)3 * B);
+    if (!rc) rc = ensure(c, c->bposmIn, (size_t)B);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->bpos3.p, bpos, (size_t)12 * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->bpar3.p, bparams, (size_t)12 * B, hipMemcpyHostToDevice, c->stream));
+    k_pack_boundary<<<blocks_for(B, 256), 256, 0, c->stream>>>(c->bpos3.p, c->bpar3.p, B,
+                                                               c->bposmIn.p);
+    for (int a = 0; a < 3; a++) {
+        c->hostBMin[a] = 3.402823466e+38f;
+        c->hostBMax[a] = -3.402823466e+38f;
+    }
+    for (int i = 0; i < B; i++)
+        for (int a = 0; a < 3; a++) {
+            c->hostBMin[a] = std::min(c->hostBMin[a], bpos[3 * i + a]);
+            c->hostBMax[a] = std::max(c->hostBMax[a], bpos[3 * i + a]);
+        }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->gridExplicit) c->gridValid = false; // re-derive the table around the new boundary
+    return SPH_OK;
+}
+
+int sph_set_colliders(SphCtx *c, const SphBox *boxes, int32_t K)
+{
+    if (!c) return SPH_E_INVALID;
+    if (K < 0 || (K > 0 && !boxes)) return fail(c, SPH_E_INVALID, "bad collider array");
+    if (K > 65536) return fail(c, SPH_E_TOOLARGE, "at most 65536 box colliders");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->nboxes = K;
+    if (K == 0) return SPH_OK;
+    int rc = ensure(c, c->boxState, (size_t)25 * K);
+    if (!rc) rc = ensure(c, c->devBoxes, (size_t)K);
+    if (!rc) rc = ensure(c, c->bodyImpulse, (size_t)6 * K);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->boxState.p, boxes, sizeof(SphBox) * (size_t)K,
+                             hipMemcpyHostToDevice, c->stream));
+    k_bodies<<<blocks_for(K, 64), 64, 0, c->stream>>>(c->boxState.p, c->devBoxes.p,
+                                                      c->bodyImpulse.p, K, 0, 0.f, 0.f, 0.f, 0.f,
+                                                      0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_get_colliders(SphCtx *c, SphBox *out, int32_t K)
+{
+    if (!c || !out) return SPH_E_INVALID;
+    if (K != c->nboxes) return fail(c, SPH_E_INVALID, "K=%d but %d colliders are set", K, c->nboxes);
+    if (K == 0) return SPH_OK;
+    HIPCHK(c, hipMemcpyAsync(out, c->boxState.p, sizeof(SphBox) * (size_t)K, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_set_grid(SphCtx *c, const SphGrid *g)
+{
+    if (!c) return SPH_E_INVALID;
+    if (!g) { // back to automatic sizing
+        c->gridExplicit = false;
+        c->gridValid = false;
+        return SPH_OK;
+    }
+    long long prod = 1;
+    for (int a = 0; a < 3; a++) {
+        if (g->dims[a] < 4) return fail(c, SPH_E_INVALID, "every grid dimension must be >= 4");
+        prod *= g->dims[a];
+    }
+    if (prod > (1ll << 30)) return fail(c, SPH_E_TOOLARGE, "cell table beyond 2^30 cells");
+    c->gridExplicit = true;
+    set_grid(c, g->origin, g->dims, c->gridValid ? c->grid.cellSize : 0.f);
+    c->gridValid = false; // cell size arrives with the first SphParams
+    c->grid.gx = g->dims[0]; c->grid.gy = g->dims[1]; c->grid.gz = g->dims[2];
+    c->grid.ox = g->origin[0]; c->grid.oy = g->origin[1]; c->grid.oz = g->origin[2];
+    c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
+    return SPH_OK;
+}
+
+int sph_get_grid(SphCtx *c, SphGrid *g)
+{
+    if (!c || !g) return SPH_E_INVALID;
+    if (!c->gridValid) return fail(c, SPH_E_INVALID, "grid not derived yet (run a stage first)");
+    g->origin[0] = c->grid.ox; g->origin[1] = c->grid.oy; g->origin[2] = c->grid.oz;
+    g->dims[0] = c->grid.gx; g->dims[1] = c->grid.gy; g->dims[2] = c->grid.gz;
+    g->cells = c->grid.cells;
+    g->keyBits = key_bits(c->grid.cells);
+    return SPH_OK;
+}
+
+int sph_upload(SphCtx *c, const float *pos, const float *vel, const float *invMass,
+               const SphParticle *params, int32_t N, float gridSize)
+{
+    if (!c) return SPH_E_INVALID;
+    if (N <= 0 || !pos || !vel || !invMass || !params)
+        return fail(c, SPH_E_INVALID, "sph_upload needs N > 0 and non-NULL arrays");
+    if (!(gridSize > 0.f) || !std::isfinite(gridSize))
+        return fail(c, SPH_E_INVALID, "gridSize must be positive and finite");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_fluid(c, N);
+    if (!rc) rc = ensure(c, c->io3a, (size_t)3 * N);
+    if (!rc) rc = ensure(c, c->io3b, (size_t)3 * N);
+    if (!rc) rc = ensure(c, c->ioU, (size_t)N);
+    if (rc) return rc;
+    build_materials(c, invMass, params, N);
+    rc = upload_mats(c, c->matRate > 0.f ? c->matRate : 4.0f);
+    if (rc) return rc;
+    c->n = N;
+    c->cur = 0;
+    HIPCHK(c, hipMemcpyAsync(c->io3a.p, pos, (size_t)12 * N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->io3b.p, vel, (size_t)12 * N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->ioU.p, c->hostMatIdx.data(), (size_t)4 * N, hipMemcpyHostToDevice,
+                             c->stream));
+    k_pack_fluid<<<blocks_for(N, 256), 256, 0, c->stream>>>(c->io3a.p, c->io3b.p, c->ioU.p,
+                                                            c->dmats.p, N, c->posm[0].p,
+                                                            c->velq[0].p, c->mat[0].p, c->oid[0].p);
+    HIPCHK(c, hipGetLastError());
+    c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
+    c->haveDensity = c->haveForce = false;
+    if (c->gridExplicit) {
+        const int o[3] = {c->grid.ox, c->grid.oy, c->grid.oz};
+        const int d[3] = {c->grid.gx, c->grid.gy, c->grid.gz};
+        set_grid(c, o, d, gridSize);
+    } else {
+        rc = auto_grid(c, gridSize);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ensure_debug(c);
+}
+
+int sph_download(SphCtx *c, float *pos_out, float *vel_out)
+{
+    if (!c) return SPH_E_INVALID;
+    if (c->n <= 0) return fail(c, SPH_E_INVALID, "no particles uploaded");
+    const int N = c->n;
+    int rc = ensure(c, c->io3a, (size_t)3 * N);
+    if (!rc) rc = ensure(c, c->io3b, (size_t)3 * N);
+    if (rc) return rc;
+    const int cur = c->cur;
+    if (pos_out) {
+        k_unpack3<<<blocks_for(N, 256), 256, 0, c->stream>>>(c->posm[cur].p, c->oid[cur].p, N,
+                                                             c->io3a.p);
+        HIPCHK(c, hipMemcpyAsync(pos_out, c->io3a.p, (size_t)12 * N, hipMemcpyDeviceToHost,
+                                 c->stream));
+    }
+    if (vel_out) {
+        k_unpack3<<<blocks_for(N, 256), 256, 0, c->stream>>>(c->velq[cur].p, c->oid[cur].p, N,
+                                                             c->io3b.p);
+        HIPCHK(c, hipMemcpyAsync(vel_out, c->io3b.p, (size_t)12 * N, hipMemcpyDeviceToHost,
+                                 c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+// ---- stages -------------------------------------------------------------------------------
+int sph_hash_position(SphCtx *c, const SphParams *p)
+{
+    int rc = sync_params(c, p);
+    if (rc) return rc;
+    rc = ensure_debug(c);
+    if (rc) return rc;
+    StageTimer t(c, SPH_T_KEYS);
+    const int N = c->n, cur = c->cur;
+    if (c->debug & SPH_DEBUG_HASHES)
+        k_keys<true><<<blocks_for(N, 256), 256, 0, c->stream>>>(c->posm[cur].p, c->oid[cur].p, N,
+                                                                c->grid, c->keysA.p, c->hashes.p,
+                                                                c->cells.p, c->keysEcs.p);
+    else
+        k_keys<false><<<blocks_for(N, 256), 256, 0, c->stream>>>(c->posm[cur].p, nullptr, N,
+                                                                 c->grid, c->keysA.p, nullptr,
+                                                                 nullptr, nullptr);
+    HIPCHK(c, hipGetLastError());
+    c->haveKeys = true;
+    c->haveSort = c->haveTable = c->ordered = false;
+    return SPH_OK;
+}
+
+int sph_radix_sort(SphCtx *c)
+{
+    if (!c) return SPH_E_INVALID;
+    if (!c->haveKeys) return fail(c, SPH_E_INVALID, "sph_radix_sort before sph_hash_position");
+    StageTimer t(c, SPH_T_SORT);
+    int rc = radix_sort(c, c->keysA.p, c->valsA.p, c->keysB.p, c->valsB.p, c->n,
+                        key_bits(c->grid.cells), &c->sortedKeys, &c->sortedVals);
+    if (rc) return rc;
+    c->haveSort = true;
+    c->haveKeys = false; // keysA may have been overwritten
+    c->haveTable = c->ordered = false;
+    return SPH_OK;
+}
+
+int sph_map_table(SphCtx *c)
+{
+    if (!c) return SPH_E_INVALID;
+    if (!c->haveSort) return fail(c, SPH_E_INVALID, "sph_map_table before sph_radix_sort");
+    int rc = ensure(c, c->table, (size_t)c->grid.cells);
+    if (rc) return rc;
+    rc = prepare_boundary(c);
+    if (rc) return rc;
+    StageTimer t(c, SPH_T_TABLE);
+    HIPCHK(c, hipMemsetAsync(c->table.p, 0, (size_t)c->grid.cells * sizeof(int2), c->stream));
+    k_map_table<<<blocks_for(c->n, 256), 256, 0, c->stream>>>(c->sortedKeys, c->n, c->table.p);
+    HIPCHK(c, hipGetLastError());
+    c->haveTable = true;
+    c->ordered = false;
+    return SPH_OK;
+}
+
+int sph_reorder(SphCtx *c)
+{
+    if (!c) return SPH_E_INVALID;
+    if (!c->haveTable) return fail(c, SPH_E_INVALID, "sph_reorder before sph_map_table");
+    if (c->ordered) return SPH_OK;
+    StageTimer t(c, SPH_T_REORDER);
+    const int N = c->n, cur = c->cur, nxt = cur ^ 1;
+    k_reorder<<<blocks_for(N, 256), 256, 0, c->stream>>>(
+        c->sortedVals, c->sortedKeys, c->table.p, N, c->posm[cur].p, c->velq[cur].p, c->mat[cur].p,
+        c->oid[cur].p, c->posm[nxt].p, c->velq[nxt].p, c->mat[nxt].p, c->oid[nxt].p);
+    HIPCHK(c, hipGetLastError());
+    c->cur = nxt;
+    c->ordered = true;
+    c->haveDensity = c->haveForce = false;
+    return SPH_OK;
+}
+
+int sph_compute_density_and_pressure(SphCtx *c, const SphParams *p)
+{
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (!c->ordered) return fail(c, SPH_E_INVALID, "density before sph_reorder");
+    rc = ensure_debug(c);
+    if (rc) return rc;
+    StageTimer t(c, SPH_T_DENSITY);
+    const int N = c->n, cur = c->cur;
+    const float4 *bp = c->nb > 0 ? c->bposm.p : nullptr;
+    const int2 *bt = c->nb > 0 ? c->btable.p : nullptr;
+    if (c->debug & SPH_DEBUG_COUNTS)
+        k_density<true><<<blocks_for(N, 64), 64, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->sortedKeys, c->table.p, bp, bt,
+            c->grid, c->dmats.p, c->rho.p, c->prs.p, c->dcount.p, N);
+    else
+        k_density<false><<<blocks_for(N, 64), 64, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->sortedKeys, c->table.p, bp, bt,
+            c->grid, c->dmats.p, c->rho.p, c->prs.p, nullptr, N);
+    HIPCHK(c, hipGetLastError());
+    c->haveDensity = true;
+    return SPH_OK;
+}
+
+int sph_compute_force(SphCtx *c, const SphParams *p)
+{
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (!c->haveDensity) return fail(c, SPH_E_INVALID, "force before density");
+    StageTimer t(c, SPH_T_FORCE);
+    const int N = c->n, cur = c->cur;
+    const float4 *bp = c->nb > 0 ? c->bposm.p : nullptr;
+    const int2 *bt = c->nb > 0 ? c->btable.p : nullptr;
+    if (c->debug & SPH_DEBUG_COUNTS)
+        k_force<true><<<blocks_for(N, 64), 64, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->rho.p, c->prs.p, c->sortedKeys,
+            c->table.p, bp, bt, c->grid, c->dmats.p, p->gravity[0], p->gravity[1], p->gravity[2],
+            c->force.p, c->fcount.p, N);
+    else
+        k_force<false><<<blocks_for(N, 64), 64, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->rho.p, c->prs.p, c->sortedKeys,
+            c->table.p, bp, bt, c->grid, c->dmats.p, p->gravity[0], p->gravity[1], p->gravity[2],
+            c->force.p, nullptr, N);
+    HIPCHK(c, hipGetLastError());
+    c->haveForce = true;
+    return SPH_OK;
+}
+
+static int launch_apply_integrate(SphCtx *c, const SphParams *p, bool apply, bool integrate)
+{
+    const int N = c->n, cur = c->cur;
+    const int nb = blocks_for(N, 256);
+#define LAUNCH_AI(A, I)                                                                          \
+    k_apply_integrate<A, I><<<nb, 256, 0, c->stream>>>(                                          \
+        c->posm[cur].p, c->velq[cur].p, c->force.p, c->rho.p, c->mat[cur].p, c->dmats.p, N,      \
+        p->dt, c->devBoxes.p, c->nboxes, p->particleRestitution, c->bodyImpulse.p)
+    if (apply && integrate) LAUNCH_AI(true, true);
+    else if (apply) LAUNCH_AI(true, false);
+    else LAUNCH_AI(false, true);
+#undef LAUNCH_AI
+    HIPCHK(c, hipGetLastError());
+    return SPH_OK;
+}
+
+static int launch_bodies(SphCtx *c, const SphParams *p)
+{
+    if (c->nboxes <= 0) return SPH_OK;
+    StageTimer t(c, SPH_T_BODIES);
+    k_bodies<<<blocks_for(c->nboxes, 64), 64, 0, c->stream>>>(
+        c->boxState.p, c->devBoxes.p, c->bodyImpulse.p, c->nboxes, 1, p->dt, p->gravity[0],
+        p->gravity[1], p->gravity[2], p->boundBodies, p->bodyMin[0], p->bodyMin[1], p->bodyMin[2],
+        p->bodyMax[0], p->bodyMax[1], p->bodyMax[2]);
+    HIPCHK(c, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_apply_force(SphCtx *c, const SphParams *p)
+{
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (!c->haveForce) return fail(c, SPH_E_INVALID, "apply_force before compute_force");
+    StageTimer t(c, SPH_T_INTEGRATE);
+    return launch_apply_integrate(c, p, true, false);
+}
+
+int sph_integrate(SphCtx *c, const SphParams *p)
+{
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (c->n <= 0) return fail(c, SPH_E_INVALID, "no particles uploaded");
+    {
+        StageTimer t(c, SPH_T_INTEGRATE);
+        rc = launch_apply_integrate(c, p, false, true);
+        if (rc) return rc;
+    }
+    c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
+    c->haveDensity = c->haveForce = false;
+    return launch_bodies(c, p);
+}
+
+int sph_step_resident(SphCtx *c, const SphParams *p, int32_t nsteps)
+{
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int s = 0; s < nsteps; s++) {
+        if ((rc = sph_hash_position(c, p))) return rc;
+        if ((rc = sph_radix_sort(c))) return rc;
+        if ((rc = sph_map_table(c))) return rc;
+        if ((rc = sph_reorder(c))) return rc;
+        if ((rc = sph_compute_density_and_pressure(c, p))) return rc;
+        if ((rc = sph_compute_force(c, p))) return rc;
+        {
+            StageTimer t(c, SPH_T_INTEGRATE);
+            if ((rc = launch_apply_integrate(c, p, true, true))) return rc;
+        }
+        c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
+        c->haveDensity = c->haveForce = false;
+        if ((rc = launch_bodies(c, p))) return rc;
+        c->tm.steps++;
+    }
+    return SPH_OK;
+}
+
+static int read_ecs(SphCtx *c, int32_t buffer, void *out);
+
+int sph_step(SphCtx *c, const SphParams *p, float *pos, float *vel, const float *invMass,
+             const SphParticle *params, int32_t N, float *densities_out, float *forces_out)
+{
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if ((rc = sph_upload(c, pos, vel, invMass, params, N, p->gridSize))) return rc;
+    if ((rc = sph_hash_position(c, p))) return rc;
+    if ((rc = sph_radix_sort(c))) return rc;
+    if ((rc = sph_map_table(c))) return rc;
+    if ((rc = sph_reorder(c))) return rc;
+    if ((rc = sph_compute_density_and_pressure(c, p))) return rc;
+    if ((rc = sph_compute_force(c, p))) return rc;
+    if (densities_out && (rc = read_ecs(c, SPH_BUF_DENSITIES, densities_out))) return rc;
+    if (forces_out && (rc = read_ecs(c, SPH_BUF_FORCES, forces_out))) return rc;
+    {
+        StageTimer t(c, SPH_T_INTEGRATE);
+        if ((rc = launch_apply_integrate(c, p, true, true))) return rc;
+    }
+    if ((rc = launch_bodies(c, p))) return rc;
+    c->tm.steps++;
+    rc = sph_download(c, pos, vel);
+    c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
+    c->haveDensity = c->haveForce = false;
+    return rc;
+}
+
+int sph_step_compat(SphCtx *c, const SphParams *p, const float *pos, const float *vel,
+                    const float *invMass, const SphParticle *params, int32_t N,
+                    float *densities_out, float *forces_out)
+{
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (!densities_out || !forces_out) return fail(c, SPH_E_INVALID, "output arrays are NULL");
+    if ((rc = sph_upload(c, pos, vel, invMass, params, N, p->gridSize))) return rc;
+    if ((rc = sph_hash_position(c, p))) return rc;
+    if ((rc = sph_radix_sort(c))) return rc;
+    if ((rc = sph_map_table(c))) return rc;
+    if ((rc = sph_reorder(c))) return rc;
+    if ((rc = sph_compute_density_and_pressure(c, p))) return rc;
+    if ((rc = sph_compute_force(c, p))) return rc;
+    if ((rc = read_ecs(c, SPH_BUF_DENSITIES, densities_out))) return rc;
+    return read_ecs(c, SPH_BUF_FORCES, forces_out);
+}
+
+// ---- inspection ---------------------------------------------------------------------------
+static int read_ecs(SphCtx *c, int32_t buffer, void *out)
+{
+    const int N = c->n, cur = c->cur;
+    int rc = ensure(c, c->io3a, (size_t)3 * N);
+    if (!rc) rc = ensure(c, c->io1, (size_t)N);
+    if (rc) return rc;
+    const int nb = blocks_for(N, 256);
+    size_t bytes = 0;
+    void *src = nullptr;
+    switch (buffer) {
+    case SPH_BUF_DENSITIES:
+        k_unpack1<float><<<nb, 256, 0, c->stream>>>(c->rho.p, c->oid[cur].p, N, c->io1.p);
+        src = c->io1.p; bytes = (size_t)4 * N; break;
+    case SPH_BUF_PRESSURES:
+        k_unpack1<float><<<nb, 256, 0, c->stream>>>(c->prs.p, c->oid[cur].p, N, c->io1.p);
+        src = c->io1.p; bytes = (size_t)4 * N; break;
+    case SPH_BUF_DENSITY_COUNTS:
+        k_unpack1<int><<<nb, 256, 0, c->stream>>>(c->dcount.p, c->oid[cur].p, N, (int *)c->io1.p);
+        src = c->io1.p; bytes = (size_t)4 * N; break;
+    case SPH_BUF_FORCE_COUNTS:
+        k_unpack1<int><<<nb, 256, 0, c->stream>>>(c->fcount.p, c->oid[cur].p, N, (int *)c->io1.p);
+        src = c->io1.p; bytes = (size_t)4 * N; break;
+    case SPH_BUF_FORCES:
+        k_unpack3<<<nb, 256, 0, c->stream>>>(c->force.p, c->oid[cur].p, N, c->io3a.p);
+        src = c->io3a.p; bytes = (size_t)12 * N; break;
+    case SPH_BUF_POSITIONS:
+        k_unpack3<<<nb, 256, 0, c->stream>>>(c->posm[cur].p, c->oid[cur].p, N, c->io3a.p);
+        src = c->io3a.p; bytes = (size_t)12 * N; break;
+    case SPH_BUF_VELOCITIES:
+        k_unpack3<<<nb, 256, 0, c->stream>>>(c->velq[cur].p, c->oid[cur].p, N, c->io3a.p);
+        src = c->io3a.p; bytes = (size_t)12 * N; break;
+    default: return fail(c, SPH_E_INVALID, "buffer %d is not an ECS-order buffer", buffer);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_read(SphCtx *c, int32_t buffer, void *out, size_t bytes)
+{
+    if (!c || !out) return SPH_E_INVALID;
+    if (c->n <= 0) return fail(c, SPH_E_INVALID, "no particles uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)c->n;
+    const void *src = nullptr;
+    size_t need = 0;
+    bool ok = true;
+    switch (buffer) {
+    case SPH_BUF_HASHES: src = c->hashes.p; need = 4 * N; ok = (c->debug & SPH_DEBUG_HASHES) && c->hashes.p; break;
+    case SPH_BUF_CELLS: src = c->cells.p; need = 12 * N; ok = (c->debug & SPH_DEBUG_HASHES) && c->cells.p; break;
+    case SPH_BUF_KEYS: src = c->keysEcs.p; need = 4 * N; ok = (c->debug & SPH_DEBUG_HASHES) && c->keysEcs.p; break;
+    case SPH_BUF_PERM: src = c->oid[c->cur].p; need = 4 * N; ok = c->ordered; break;
+    case SPH_BUF_SORTED_KEYS: src = c->sortedKeys; need = 4 * N; ok = c->haveSort; break;
+    case SPH_BUF_TABLE: src = c->table.p; need = (size_t)8 * c->grid.cells; ok = c->haveTable; break;
+    case SPH_BUF_BOUNDARY_PERM: src = c->bperm; need = (size_t)4 * c->nb; ok = !c->boundaryDirty && c->nb > 0; break;
+    case SPH_BUF_BOUNDARY_TABLE: src = c->btable.p; need = (size_t)8 * c->grid.cells; ok = !c->boundaryDirty; break;
+    case SPH_BUF_DENSITIES: case SPH_BUF_PRESSURES:
+        if (!c->haveDensity) return fail(c, SPH_E_INVALID, "densities not computed");
+        if (bytes != 4 * N) return fail(c, SPH_E_INVALID, "size mismatch: need %zu bytes", 4 * N);
+        return read_ecs(c, buffer, out);
+    case SPH_BUF_DENSITY_COUNTS:
+        if (!c->haveDensity || !(c->debug & SPH_DEBUG_COUNTS)) return fail(c, SPH_E_INVALID, "density counts not computed (SPH_DEBUG_COUNTS)");
+        if (bytes != 4 * N) return fail(c, SPH_E_INVALID, "size mismatch: need %zu bytes", 4 * N);
+        return read_ecs(c, buffer, out);
+    case SPH_BUF_FORCE_COUNTS:
+        if (!c->haveForce || !(c->debug & SPH_DEBUG_COUNTS)) return fail(c, SPH_E_INVALID, "force counts not computed (SPH_DEBUG_COUNTS)");
+        if (bytes != 4 * N) return fail(c, SPH_E_INVALID, "size mismatch: need %zu bytes", 4 * N);
+        return read_ecs(c, buffer, out);
+    case SPH_BUF_FORCES:
+        if (!c->haveForce) return fail(c, SPH_E_INVALID, "forces not computed");
+        if (bytes != 12 * N) return fail(c, SPH_E_INVALID, "size mismatch: need %zu bytes", 12 * N);
+        return read_ecs(c, buffer, out);
+    case SPH_BUF_POSITIONS: case SPH_BUF_VELOCITIES:
+        if (bytes != 12 * N) return fail(c, SPH_E_INVALID, "size mismatch: need %zu bytes", 12 * N);
+        return read_ecs(c, buffer, out);
+    default: return fail(c, SPH_E_INVALID, "unknown buffer %d", buffer);
+    }
+    if (!ok || !src) return fail(c, SPH_E_INVALID, "buffer %d is not available at this point", buffer);
+    if (bytes != need) return fail(c, SPH_E_INVALID, "size mismatch: need %zu bytes", need);
+    HIPCHK(c, hipMemcpyAsync(out, src, need, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_find_bounds(SphCtx *c, float gridSize, float mn[3], float mx[3])
+{
+    if (!c || !mn || !mx) return SPH_E_INVALID;
+    if (c->n <= 0) return fail(c, SPH_E_INVALID, "no particles uploaded");
+    int rc = bounds_of(c, c->posm[c->cur].p, c->n, mn, mx);
+    if (rc) return rc;
+    if (c->nb > 0) {
+        float bmn[3], bmx[3];
+        rc = bounds_of(c, c->bposmIn.p, c->nb, bmn, bmx);
+        if (rc) return rc;
+        for (int a = 0; a < 3; a++) {
+            mn[a] = std::min(mn[a], bmn[a]);
+            mx[a] = std::max(mx[a], bmx[a]);
+        }
+    }
+    for (int a = 0; a < 3; a++) { // FluidSPHUtils.cs:85-92
+        volatile float lo = mn[a] / gridSize, hi = mx[a] / gridSize;
+        volatile float l = floorf(lo) * gridSize, h = ceilf(hi) * gridSize;
+        mn[a] = l;
+        mx[a] = h + 1.0f;
+    }
+    return SPH_OK;
+}
+
+int sph_sort_pairs(SphCtx *c, const uint32_t *keys, int32_t n, int32_t bits, uint32_t *perm_out,
+                   uint32_t *keys_out)
+{
+    if (!c) return SPH_E_INVALID;
+    if (n < 0 || bits < 1 || bits > 32 || (n > 0 && !keys))
+        return fail(c, SPH_E_INVALID, "bad sort arguments");
+    if (n == 0) return SPH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf<uint32_t> ka, kb, va, vb;
+    int rc = ensure(c, ka, (size_t)n, false);
+    if (!rc) rc = ensure(c, kb, (size_t)n, false);
+    if (!rc) rc = ensure(c, va, (size_t)n, false);
+    if (!rc) rc = ensure(c, vb, (size_t)n, false);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(ka.p, keys, (size_t)4 * n, hipMemcpyHostToDevice, c->stream);
+        uint32_t *sk = nullptr, *sv = nullptr;
+        if (e == hipSuccess) rc = radix_sort(c, ka.p, va.p, kb.p, vb.p, n, bits, &sk, &sv);
+        if (e == hipSuccess && !rc && perm_out)
+            e = hipMemcpyAsync(perm_out, sv, (size_t)4 * n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && !rc && keys_out)
+            e = hipMemcpyAsync(keys_out, sk, (size_t)4 * n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess && !rc) rc = fail(c, SPH_E_DEVICE, "sort: %s", hipGetErrorString(e));
+    }
+    release(ka); release(kb); release(va); release(vb);
+    return rc;
+}
+
+int sph_get_timings(SphCtx *c, SphTimings *out)
+{
+    if (!c || !out) return SPH_E_INVALID;
+    int rc = collect_timings(c);
+    if (rc) return rc;
+    *out = c->tm;
+    return SPH_OK;
+}
+
+int sph_reset_timings(SphCtx *c)
+{
+    if (!c) return SPH_E_INVALID;
+    int rc = collect_timings(c);
+    if (rc) return rc;
+    std::memset(&c->tm, 0, sizeof(c->tm));
+    return SPH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,337 @@
+"""ctypes binding of libsphfluid.so (include/sphfluid.h), 1:1 with the C ABI.
+
+This is what a P/Invoke layer in the reference's C# host would look like; here it serves the
+Python harnesses (tests, bench).  There is no fallback: if the shared library is missing, import
+fails loudly (build it with `python -m fluidsimulation_amd.build` or __graft_entry__.build()).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsphfluid.so")
+
+SPH_OK = 0
+SPH_E_INVALID, SPH_E_NOMEM, SPH_E_DEVICE, SPH_E_NODEVICE, SPH_E_TOOLARGE = -1, -2, -3, -4, -5
+
+(SPH_T_KEYS, SPH_T_SORT, SPH_T_TABLE, SPH_T_REORDER, SPH_T_DENSITY, SPH_T_FORCE, SPH_T_INTEGRATE,
+ SPH_T_BODIES, SPH_T_COUNT) = range(9)
+STAGE_NAMES = ["keys", "sort", "table", "reorder", "density", "force", "integrate", "bodies"]
+
+(SPH_BUF_HASHES, SPH_BUF_CELLS, SPH_BUF_KEYS, SPH_BUF_PERM, SPH_BUF_SORTED_KEYS, SPH_BUF_TABLE,
+ SPH_BUF_DENSITIES, SPH_BUF_PRESSURES, SPH_BUF_FORCES, SPH_BUF_DENSITY_COUNTS,
+ SPH_BUF_FORCE_COUNTS, SPH_BUF_POSITIONS, SPH_BUF_VELOCITIES, SPH_BUF_BOUNDARY_PERM,
+ SPH_BUF_BOUNDARY_TABLE) = range(15)
+
+SPH_DEBUG_HASHES, SPH_DEBUG_COUNTS = 1, 2
+
+# every symbol include/sphfluid.h declares (tests check that the library exports them all)
+EXPORTS = [
+    "sph_create", "sph_destroy", "sph_last_error", "sph_device_name", "sph_set_debug",
+    "sph_synchronize", "sph_find_grid_size", "sph_set_boundary", "sph_set_colliders",
+    "sph_get_colliders", "sph_set_grid", "sph_get_grid", "sph_upload", "sph_download",
+    "sph_hash_position", "sph_radix_sort", "sph_map_table", "sph_reorder",
+    "sph_compute_density_and_pressure", "sph_compute_force", "sph_apply_force", "sph_integrate",
+    "sph_step_resident", "sph_step", "sph_step_compat", "sph_read", "sph_find_bounds",
+    "sph_sort_pairs", "sph_get_timings", "sph_reset_timings",
+]
+
+
+class SphParams(C.Structure):
+    _fields_ = [("dt", C.c_float), ("kernelRadiusRate", C.c_float), ("gravity", C.c_float * 3),
+                ("gridSize", C.c_float), ("particleRestitution", C.c_float),
+                ("boundBodies", C.c_int32), ("bodyMin", C.c_float * 3),
+                ("bodyMax", C.c_float * 3)]
+
+
+class SphConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("maxCells", C.c_int32), ("enableTimings", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class SphGrid(C.Structure):
+    _fields_ = [("origin", C.c_int32 * 3), ("dims", C.c_int32 * 3), ("keyBits", C.c_int32),
+                ("cells", C.c_int32)]
+
+
+class SphTimings(C.Structure):
+    _fields_ = [("ms", C.c_double * SPH_T_COUNT), ("launches", C.c_int64 * SPH_T_COUNT),
+                ("steps", C.c_int64)]
+
+
+class SphError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"libsphfluid error {code}: {text}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen libsphfluid.so and declare the prototypes.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run __graft_entry__.build() "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    lib.sph_create.argtypes = [C.POINTER(SphConfig), C.POINTER(vp)]
+    lib.sph_destroy.argtypes = [vp]
+    lib.sph_last_error.argtypes = [vp]
+    lib.sph_last_error.restype = C.c_char_p
+    lib.sph_device_name.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32)]
+    lib.sph_set_debug.argtypes = [vp, i32]
+    lib.sph_synchronize.argtypes = [vp]
+    lib.sph_find_grid_size.argtypes = [vp, vp, i32, f32]
+    lib.sph_find_grid_size.restype = f32
+    lib.sph_set_boundary.argtypes = [vp, vp, vp, i32]
+    lib.sph_set_colliders.argtypes = [vp, vp, i32]
+    lib.sph_get_colliders.argtypes = [vp, vp, i32]
+    lib.sph_set_grid.argtypes = [vp, C.POINTER(SphGrid)]
+    lib.sph_get_grid.argtypes = [vp, C.POINTER(SphGrid)]
+    lib.sph_upload.argtypes = [vp, vp, vp, vp, vp, i32, f32]
+    lib.sph_download.argtypes = [vp, vp, vp]
+    for name in ("sph_hash_position", "sph_compute_density_and_pressure", "sph_compute_force",
+                 "sph_apply_force", "sph_integrate"):
+        getattr(lib, name).argtypes = [vp, C.POINTER(SphParams)]
+    for name in ("sph_radix_sort", "sph_map_table", "sph_reorder", "sph_reset_timings"):
+        getattr(lib, name).argtypes = [vp]
+    lib.sph_step_resident.argtypes = [vp, C.POINTER(SphParams), i32]
+    lib.sph_step.argtypes = [vp, C.POINTER(SphParams), vp, vp, vp, vp, i32, vp, vp]
+    lib.sph_step_compat.argtypes = [vp, C.POINTER(SphParams), vp, vp, vp, vp, i32, vp, vp]
+    lib.sph_read.argtypes = [vp, i32, vp, C.c_size_t]
+    lib.sph_find_bounds.argtypes = [vp, f32, vp, vp]
+    lib.sph_sort_pairs.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.sph_get_timings.argtypes = [vp, C.POINTER(SphTimings)]
+    for name in EXPORTS:
+        if name not in ("sph_last_error", "sph_find_grid_size"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def make_params(grid_size, dt=1.0 / 60.0, rate=4.0, gravity=(0.0, -9.81, 0.0),
+                particle_restitution=0.5, body_bounds=None):
+    p = SphParams()
+    p.dt = dt
+    p.kernelRadiusRate = rate
+    p.gravity[:] = gravity
+    p.gridSize = grid_size
+    p.particleRestitution = particle_restitution
+    if body_bounds is not None:
+        p.boundBodies = 1
+        p.bodyMin[:] = [float(v) for v in body_bounds[0]]
+        p.bodyMax[:] = [float(v) for v in body_bounds[1]]
+    return p
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if shape is None else a.reshape(shape)
+
+
+class Context:
+    """Thin RAII wrapper over SphCtx*; methods map 1:1 to the C entry points."""
+
+    def __init__(self, device=0, max_cells=0, timings=False):
+        self.lib = load()
+        cfg = SphConfig(device, max_cells, 1 if timings else 0, 0)
+        h = C.c_void_p()
+        rc = self.lib.sph_create(C.byref(cfg), C.byref(h))
+        if rc != SPH_OK:
+            raise SphError(rc, self.lib.sph_last_error(None).decode())
+        self.h = h
+        self.n = 0
+        self.nboxes = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sph_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != SPH_OK:
+            raise SphError(rc, self.lib.sph_last_error(self.h).decode())
+
+    # -- scene state
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        cus = C.c_int32()
+        self._chk(self.lib.sph_device_name(self.h, buf, 256, C.byref(cus)))
+        return buf.value.decode(), cus.value
+
+    def set_debug(self, flags):
+        self._chk(self.lib.sph_set_debug(self.h, flags))
+
+    def synchronize(self):
+        self._chk(self.lib.sph_synchronize(self.h))
+
+    def set_boundary(self, bpos, bparams):
+        bpos = _f32(bpos, (-1, 3))
+        bparams = _f32(bparams, (-1, 3))
+        self._chk(self.lib.sph_set_boundary(self.h, _ptr(bpos), _ptr(bparams), len(bpos)))
+
+    def set_colliders(self, boxes):
+        boxes = _f32(boxes, (-1, 25))
+        self.nboxes = len(boxes)
+        self._chk(self.lib.sph_set_colliders(self.h, _ptr(boxes), len(boxes)))
+
+    def get_colliders(self):
+        out = np.empty((self.nboxes, 25), np.float32)
+        self._chk(self.lib.sph_get_colliders(self.h, _ptr(out), self.nboxes))
+        return out
+
+    def set_grid(self, origin, dims):
+        if origin is None:
+            self._chk(self.lib.sph_set_grid(self.h, None))
+            return
+        g = SphGrid()
+        g.origin[:] = [int(v) for v in origin]
+        g.dims[:] = [int(v) for v in dims]
+        self._chk(self.lib.sph_set_grid(self.h, C.byref(g)))
+
+    def get_grid(self):
+        g = SphGrid()
+        self._chk(self.lib.sph_get_grid(self.h, C.byref(g)))
+        return list(g.origin), list(g.dims), g.keyBits, g.cells
+
+    def upload(self, pos, vel, inv_mass, params, grid_size):
+        pos, vel = _f32(pos, (-1, 3)), _f32(vel, (-1, 3))
+        inv_mass, params = _f32(inv_mass, (-1,)), _f32(params, (-1, 4))
+        self.n = len(pos)
+        assert len(vel) == self.n and len(inv_mass) == self.n and len(params) == self.n
+        self._chk(self.lib.sph_upload(self.h, _ptr(pos), _ptr(vel), _ptr(inv_mass), _ptr(params),
+                                      self.n, grid_size))
+
+    def download(self):
+        pos = np.empty((self.n, 3), np.float32)
+        vel = np.empty((self.n, 3), np.float32)
+        self._chk(self.lib.sph_download(self.h, _ptr(pos), _ptr(vel)))
+        return pos, vel
+
+    # -- stages (FluidSPHByGPUSystem.cs:242-247 names)
+    def hash_position(self, p):
+        self._chk(self.lib.sph_hash_position(self.h, C.byref(p)))
+
+    def radix_sort(self):
+        self._chk(self.lib.sph_radix_sort(self.h))
+
+    def map_table(self):
+        self._chk(self.lib.sph_map_table(self.h))
+
+    def reorder(self):
+        self._chk(self.lib.sph_reorder(self.h))
+
+    def compute_density_and_pressure(self, p):
+        self._chk(self.lib.sph_compute_density_and_pressure(self.h, C.byref(p)))
+
+    def compute_force(self, p):
+        self._chk(self.lib.sph_compute_force(self.h, C.byref(p)))
+
+    def apply_force(self, p):
+        self._chk(self.lib.sph_apply_force(self.h, C.byref(p)))
+
+    def integrate(self, p):
+        self._chk(self.lib.sph_integrate(self.h, C.byref(p)))
+
+    def step_resident(self, p, nsteps=1):
+        self._chk(self.lib.sph_step_resident(self.h, C.byref(p), nsteps))
+
+    def step(self, p, pos, vel, inv_mass, params, want_densities=False, want_forces=False):
+        pos, vel = _f32(pos, (-1, 3)).copy(), _f32(vel, (-1, 3)).copy()
+        inv_mass, params = _f32(inv_mass, (-1,)), _f32(params, (-1, 4))
+        n = len(pos)
+        self.n = n
+        dens = np.empty(n, np.float32) if want_densities else None
+        forces = np.empty((n, 3), np.float32) if want_forces else None
+        self._chk(self.lib.sph_step(self.h, C.byref(p), _ptr(pos), _ptr(vel), _ptr(inv_mass),
+                                    _ptr(params), n, _ptr(dens), _ptr(forces)))
+        return pos, vel, dens, forces
+
+    def step_compat(self, p, pos, vel, inv_mass, params):
+        pos, vel = _f32(pos, (-1, 3)), _f32(vel, (-1, 3))
+        inv_mass, params = _f32(inv_mass, (-1,)), _f32(params, (-1, 4))
+        n = len(pos)
+        self.n = n
+        dens = np.empty(n, np.float32)
+        forces = np.empty((n, 3), np.float32)
+        self._chk(self.lib.sph_step_compat(self.h, C.byref(p), _ptr(pos), _ptr(vel),
+                                           _ptr(inv_mass), _ptr(params), n, _ptr(dens),
+                                           _ptr(forces)))
+        return dens, forces
+
+    # -- inspection
+    def read(self, buffer):
+        n = self.n
+        if buffer in (SPH_BUF_HASHES, SPH_BUF_KEYS, SPH_BUF_PERM, SPH_BUF_SORTED_KEYS):
+            out = np.empty(n, np.uint32)
+        elif buffer == SPH_BUF_CELLS:
+            out = np.empty((n, 3), np.int32)
+        elif buffer in (SPH_BUF_TABLE, SPH_BUF_BOUNDARY_TABLE):
+            out = np.empty((self.get_grid()[3], 2), np.int32)
+        elif buffer in (SPH_BUF_DENSITIES, SPH_BUF_PRESSURES):
+            out = np.empty(n, np.float32)
+        elif buffer in (SPH_BUF_DENSITY_COUNTS, SPH_BUF_FORCE_COUNTS):
+            out = np.empty(n, np.int32)
+        elif buffer in (SPH_BUF_FORCES, SPH_BUF_POSITIONS, SPH_BUF_VELOCITIES):
+            out = np.empty((n, 3), np.float32)
+        else:
+            raise ValueError(buffer)
+        self._chk(self.lib.sph_read(self.h, buffer, _ptr(out), out.nbytes))
+        return out
+
+    def read_boundary_perm(self, b):
+        out = np.empty(b, np.uint32)
+        self._chk(self.lib.sph_read(self.h, SPH_BUF_BOUNDARY_PERM, _ptr(out), out.nbytes))
+        return out
+
+    def find_bounds(self, grid_size):
+        mn = np.empty(3, np.float32)
+        mx = np.empty(3, np.float32)
+        self._chk(self.lib.sph_find_bounds(self.h, grid_size, _ptr(mn), _ptr(mx)))
+        return mn, mx
+
+    def sort_pairs(self, keys, key_bits=32):
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        perm = np.empty(len(keys), np.uint32)
+        skeys = np.empty(len(keys), np.uint32)
+        self._chk(self.lib.sph_sort_pairs(self.h, _ptr(keys), len(keys), key_bits, _ptr(perm),
+                                          _ptr(skeys)))
+        return perm, skeys
+
+    def timings(self):
+        t = SphTimings()
+        self._chk(self.lib.sph_get_timings(self.h, C.byref(t)))
+        return {"ms": {STAGE_NAMES[i]: t.ms[i] for i in range(SPH_T_COUNT)},
+                "launches": {STAGE_NAMES[i]: t.launches[i] for i in range(SPH_T_COUNT)},
+                "steps": t.steps}
+
+    def reset_timings(self):
+        self._chk(self.lib.sph_reset_timings(self.h))
+
+
+def find_grid_size(params, chunk_first, rate=4.0):
+    lib = load()
+    params = _f32(params, (-1, 4))
+    chunk_first = np.ascontiguousarray(chunk_first, dtype=np.int32)
+    return float(lib.sph_find_grid_size(_ptr(params), _ptr(chunk_first), len(chunk_first), rate))

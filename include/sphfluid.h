@@ -1,0 +1,227 @@
+/*
+ * sphfluid.h -- C ABI of libsphfluid.so: the MI355X (gfx950) SPH fluid step.
+ *
+ * This is the drop-in boundary for the one hot path of Acceyuriko/FluidSimulation: the per-step
+ * SPH update.  The reference has no FFI; the seam this library sits behind is the compute-shader
+ * binding set of its GPU system (all citations relative to the reference checkout):
+ *   Assets/Scripts/FluidSPHByGPUSystem.cs:227-252   upload, six dispatches, blocking readback
+ *   Assets/Resources/FluidSolver.compute            the six kernels
+ * and the results must equal those of its CPU/Burst path:
+ *   Assets/Scripts/FluidSPHByCPUSystem.cs:258-333, Assets/Scripts/FluidSPHUtils.cs.
+ * A C# system P/Invokes these entry points (binding stub: INTEGRATION.md).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * SPH_E_* code and never throws; sph_last_error() gives the text.  Host arrays are caller-owned
+ * and not retained past the call; all device memory is owned by the opaque SphCtx.  One context
+ * per world, one HIP stream per context, calls on one context are not re-entrant.  There is no
+ * CPU fallback: if no gfx950 device is usable sph_create fails.
+ */
+#ifndef SPHFLUID_H
+#define SPHFLUID_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_API __attribute__((visibility("default")))
+
+enum {
+    SPH_OK = 0,
+    SPH_E_INVALID = -1,   /* bad argument / call order */
+    SPH_E_NOMEM = -2,     /* device or host allocation failed */
+    SPH_E_DEVICE = -3,    /* HIP runtime error */
+    SPH_E_NODEVICE = -4,  /* no usable gfx950 device */
+    SPH_E_TOOLARGE = -5   /* size beyond a stated limit */
+};
+
+/* FluidParticleComponent, Assets/Scripts/FluidParticleComponent.cs:9-12 (= HLSL Particle,
+ * FluidSolver.compute:114-120): 16 bytes, blittable. */
+typedef struct SphParticle {
+    float radius;
+    float restDensity;
+    float viscosity;
+    float gasConstant;
+} SphParticle;
+
+/* BoundaryParticleComponent, Assets/Scripts/BoundaryParticleComponent.cs:6-8 (= HLSL
+ * BoundaryParticle, FluidSolver.compute:182-187): 12 bytes. */
+typedef struct SphBoundaryParticle {
+    float radius;
+    float mass;
+    float restDensity;
+} SphBoundaryParticle;
+
+/* Per-step scalars.  kernelRadiusRate: FluidSPHUtils.cs:128 (4).  gridSize: the result of
+ * FindGridSizeJob (FluidSPHUtils.cs:28-44; see sph_find_grid_size).  gravity: hard-coded
+ * (0,-9.81,0) in the reference (FluidSPHByCPUSystem.cs:140).  dt: 1/FPS (:266,:323). */
+typedef struct SphParams {
+    float dt;
+    float kernelRadiusRate;
+    float gravity[3];
+    float gridSize;
+    float particleRestitution; /* Particle.prefab:142-146 (0.5, combine = max)            */
+    int32_t boundBodies;       /* !=0: keep dynamic boxes' AABBs inside [bodyMin,bodyMax]  */
+    float bodyMin[3];
+    float bodyMax[3];
+} SphParams;
+
+/* Oriented box collider / rigid body (row I; Unity Physics / Havok in the reference, configured
+ * by Wall.prefab:99-279 and ConvertedSubScene.unity:704-885).  25 floats = 100 bytes. */
+typedef struct SphBox {
+    float center[3];
+    float rot[4];          /* unit quaternion x,y,z,w, body -> world */
+    float halfExtents[3];
+    float linVel[3];
+    float angVel[3];
+    float invMass;         /* 0 and invInertia 0 => static */
+    float invInertia[3];   /* body-space diagonal */
+    float restitution;
+    float friction;        /* carried; particle friction is 0 with combine = min */
+    float linDamping;
+    float angDamping;
+    float gravityFactor;
+} SphBox;
+
+typedef struct SphConfig {
+    int32_t device;          /* HIP device ordinal */
+    int32_t maxCells;        /* cap on the periodic cell table (0 = default 1<<25)  */
+    int32_t enableTimings;   /* record HIP events per stage (sph_get_timings)        */
+    int32_t reserved;
+} SphConfig;
+
+/* Periodic cell table the dense sort key is built on (DESIGN.md "cell keys").  A particle in
+ * quantised cell c (FluidSPHUtils.cs:236-243) gets key ((z*dims[1]+y)*dims[0]+x) with
+ * (x,y,z) = (c - origin) mod dims. */
+typedef struct SphGrid {
+    int32_t origin[3];
+    int32_t dims[3];
+    int32_t keyBits; /* ceil(log2(dims product)) */
+    int32_t cells;   /* dims product */
+} SphGrid;
+
+/* stage indices of SphTimings.ms */
+enum {
+    SPH_T_KEYS = 0, SPH_T_SORT, SPH_T_TABLE, SPH_T_REORDER, SPH_T_DENSITY, SPH_T_FORCE,
+    SPH_T_INTEGRATE, SPH_T_BODIES, SPH_T_COUNT
+};
+typedef struct SphTimings {
+    double ms[SPH_T_COUNT];     /* summed device time per stage since sph_reset_timings */
+    int64_t launches[SPH_T_COUNT];
+    int64_t steps;
+} SphTimings;
+
+/* named device buffers readable with sph_read (mirrors the named ComputeBuffers of
+ * FluidSPHByGPUSystem.cs:22-54).  "ECS order" = the order of the arrays given to sph_upload. */
+enum {
+    SPH_BUF_HASHES = 0,      /* u32[N]   FNV-1 hash of the quantised cell, ECS order            */
+    SPH_BUF_CELLS,           /* i32[N*3] quantised cell, ECS order                              */
+    SPH_BUF_KEYS,            /* u32[N]   dense key, ECS order                                   */
+    SPH_BUF_PERM,            /* u32[N]   sorted slot -> ECS id (stable by key, ties by id)      */
+    SPH_BUF_SORTED_KEYS,     /* u32[N]                                                          */
+    SPH_BUF_TABLE,           /* i32[cells*2] (start,end) per key, (0,0) when empty              */
+    SPH_BUF_DENSITIES,       /* f32[N]   ECS order                                              */
+    SPH_BUF_PRESSURES,       /* f32[N]   ECS order                                              */
+    SPH_BUF_FORCES,          /* f32[N*3] ECS order                                              */
+    SPH_BUF_DENSITY_COUNTS,  /* i32[N]   neighbours with d2 < h2 (self + boundary included)     */
+    SPH_BUF_FORCE_COUNTS,    /* i32[N]   neighbours with length < h (j != i, boundary included) */
+    SPH_BUF_POSITIONS,       /* f32[N*3] ECS order                                              */
+    SPH_BUF_VELOCITIES,      /* f32[N*3] ECS order                                              */
+    SPH_BUF_BOUNDARY_PERM,   /* u32[B]                                                          */
+    SPH_BUF_BOUNDARY_TABLE   /* i32[cells*2]                                                    */
+};
+
+typedef struct SphCtx SphCtx;
+
+/* debug flags for sph_set_debug: extra parity outputs, off in production */
+enum {
+    SPH_DEBUG_HASHES = 1, /* hash_position also writes SPH_BUF_HASHES / SPH_BUF_CELLS        */
+    SPH_DEBUG_COUNTS = 2  /* density / force kernels also write the neighbour-count buffers  */
+};
+
+/* ---- life cycle --------------------------------------------------------------------------
+ * sph_create replaces OnCreate + the ComputeBuffer (re)allocation of
+ * FluidSPHByGPUSystem.cs:59-68,96-157; sph_destroy replaces OnDestroy (:369-399).  Device
+ * buffers grow geometrically with the particle count. */
+SPH_API int sph_create(const SphConfig *cfg, SphCtx **out);
+SPH_API int sph_destroy(SphCtx *ctx);
+/* ctx may be NULL: text of the last failure of sph_create on this thread */
+SPH_API const char *sph_last_error(const SphCtx *ctx);
+SPH_API int sph_device_name(SphCtx *ctx, char *name, size_t cap, int32_t *compute_units);
+SPH_API int sph_set_debug(SphCtx *ctx, int32_t flags);
+SPH_API int sph_synchronize(SphCtx *ctx);
+
+/* ---- host-side helpers --------------------------------------------------------------------
+ * FindGridSizeJob (FluidSPHUtils.cs:28-44, start value :172-173): chunk_first[c] is the index
+ * of the first particle of ECS chunk c. */
+SPH_API float sph_find_grid_size(const SphParticle *params, const int32_t *chunk_first,
+                                 int32_t nchunks, float kernelRadiusRate);
+
+/* ---- scene state --------------------------------------------------------------------------
+ * sph_set_boundary: BoundaryPositions / BoundaryParticles buffers (FluidSPHByGPUSystem.cs
+ * :186-201,232-233).  Static: uploaded and sorted once, not every step. */
+SPH_API int sph_set_boundary(SphCtx *ctx, const float *bpos /* B*3 */,
+                             const SphBoundaryParticle *bparams /* B */, int32_t B);
+SPH_API int sph_set_colliders(SphCtx *ctx, const SphBox *boxes, int32_t K);
+SPH_API int sph_get_colliders(SphCtx *ctx, SphBox *boxes_out, int32_t K);
+/* explicit periodic cell table (every dim >= 4); without it the table is sized from the
+ * particles' bounds at sph_upload */
+SPH_API int sph_set_grid(SphCtx *ctx, const SphGrid *grid);
+SPH_API int sph_get_grid(SphCtx *ctx, SphGrid *grid_out);
+
+/* Positions / Masses(=inverse mass) / Velocities / Particles buffers
+ * (FluidSPHByGPUSystem.cs:164-181,227-230).  The order of these arrays is "ECS order". */
+SPH_API int sph_upload(SphCtx *ctx, const float *pos /* N*3 */, const float *vel /* N*3 */,
+                       const float *invMass /* N */, const SphParticle *params /* N */,
+                       int32_t N, float gridSize);
+SPH_API int sph_download(SphCtx *ctx, float *pos_out /* N*3 */, float *vel_out /* N*3 */);
+
+/* ---- stages on the device-resident state --------------------------------------------------
+ * One entry point per dispatch of FluidSPHByGPUSystem.cs:242-247 (same names), plus the two
+ * CPU-side jobs that follow it.  Asynchronous on the context's stream. */
+SPH_API int sph_hash_position(SphCtx *ctx, const SphParams *p);   /* HashPosition   :269-277 */
+SPH_API int sph_radix_sort(SphCtx *ctx);          /* replaces BitonicSort        :279-299 */
+SPH_API int sph_map_table(SphCtx *ctx);           /* ClearTable + MapTable       :301-316 */
+SPH_API int sph_reorder(SphCtx *ctx);             /* gather into sorted SoA (the reference
+                                                     indirects through IndexMap instead,
+                                                     FluidSolver.compute:156-166)           */
+SPH_API int sph_compute_density_and_pressure(SphCtx *ctx, const SphParams *p); /* :318-331 */
+SPH_API int sph_compute_force(SphCtx *ctx, const SphParams *p);                /* :333-348 */
+SPH_API int sph_apply_force(SphCtx *ctx, const SphParams *p);  /* ApplyForceJob,
+                                                     FluidSPHUtils.cs:105-124              */
+SPH_API int sph_integrate(SphCtx *ctx, const SphParams *p);    /* row I: x += v dt, box
+                                                     colliders, rigid bodies (Unity Physics
+                                                     step in the reference)                */
+/* the whole per-frame sequence (FluidSPHByCPUSystem.cs:258-333 + the physics step), nsteps
+ * times, without touching the host */
+SPH_API int sph_step_resident(SphCtx *ctx, const SphParams *p, int32_t nsteps);
+
+/* ---- one-call host round trips ------------------------------------------------------------
+ * sph_step: upload, one full step, download; pos/vel are in/out, densities_out (N) and
+ * forces_out (N*3) may be NULL.  Synchronous on return (as WaitForCompletion, :251-252). */
+SPH_API int sph_step(SphCtx *ctx, const SphParams *p, float *pos, float *vel,
+                     const float *invMass, const SphParticle *params, int32_t N,
+                     float *densities_out, float *forces_out);
+/* sph_step_compat: exactly the span FluidSPHByGPUSystem.cs:227-252 -- upload, the dispatches up
+ * to ComputeForce, readback of Densities and Forces -- so the caller's unmodified ApplyForceJob
+ * (:254-262) and physics step finish the frame. */
+SPH_API int sph_step_compat(SphCtx *ctx, const SphParams *p, const float *pos, const float *vel,
+                            const float *invMass, const SphParticle *params, int32_t N,
+                            float *densities_out, float *forces_out);
+
+/* ---- parity / inspection ------------------------------------------------------------------ */
+SPH_API int sph_read(SphCtx *ctx, int32_t buffer, void *out, size_t bytes);
+/* FindBoundsJob's snapped AABB (FluidSPHUtils.cs:57-93) of the resident fluid + boundary */
+SPH_API int sph_find_bounds(SphCtx *ctx, float gridSize, float mn_out[3], float mx_out[3]);
+/* the radix sort on its own: stable ascending sort of ids 0..n-1 by the low key_bits of keys */
+SPH_API int sph_sort_pairs(SphCtx *ctx, const uint32_t *keys, int32_t n, int32_t key_bits,
+                           uint32_t *perm_out, uint32_t *sorted_keys_out);
+SPH_API int sph_get_timings(SphCtx *ctx, SphTimings *out); /* synchronises */
+SPH_API int sph_reset_timings(SphCtx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPHFLUID_H */

@@ -1,0 +1,55 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+from fluidsimulation_amd import native, scene
+
+# BASELINE.json: "positions, velocities and densities within 1e-5 relative ... in fp32"
+RTOL = 1e-5
+
+
+def assert_close(got, want, rtol=RTOL, scale=None, what=""):
+    """|got - want| <= rtol * max(|want|, scale).  scale defaults to the largest magnitude in
+    `want`: sums with cancellation (forces) are compared relative to the size of their terms."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    if scale is None:
+        scale = float(np.max(np.abs(want))) if want.size else 0.0
+    tol = rtol * np.maximum(np.abs(want), scale)
+    err = np.abs(got - want)
+    bad = ~(err <= tol)
+    if np.any(bad):
+        i = int(np.argmax(err / np.maximum(tol, 1e-300)))
+        raise AssertionError(f"{what}: {int(bad.sum())} of {got.size} beyond {rtol:g} relative; "
+                             f"worst at flat index {i}: got {got.flat[i]!r} want {want.flat[i]!r} "
+                             f"(scale {scale:g})")
+
+
+def jittered_block(nx, ny, nz, seed, amplitude=0.02, with_boundary=True):
+    sc = scene.dam_break(nx, ny, nz, jitter_seed=seed)
+    if amplitude != 0.02:
+        sc = scene.dam_break(nx, ny, nz)
+        sc.pos = scene.jitter(sc.pos, seed, amplitude)
+    if not with_boundary:
+        sc.bpos = sc.bpos[:0]
+        sc.bparams = sc.bparams[:0]
+    return sc
+
+
+def load_scene(ctx, sc, debug=native.SPH_DEBUG_HASHES | native.SPH_DEBUG_COUNTS,
+               colliders=False):
+    ctx.set_debug(debug)
+    ctx.set_boundary(sc.bpos, sc.bparams)
+    if colliders:
+        ctx.set_colliders(sc.boxes)
+    ctx.upload(sc.pos, sc.vel, sc.inv_mass, sc.params, sc.grid_size)
+    return native.make_params(sc.grid_size)
+
+
+def run_to_force(ctx, p):
+    ctx.hash_position(p)
+    ctx.radix_sort()
+    ctx.map_table()
+    ctx.reorder()
+    ctx.compute_density_and_pressure(p)
+    ctx.compute_force(p)
