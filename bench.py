@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-updates/s of the SPH step on MI355X, with roofline and CPU baseline.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 launched by torch.distributed.run,
+one rank per GPU) prints ONE JSON line on rank 0.  A step = one whole SPH step (keys, radix sort,
+cell table, reorder, density/pressure, force, apply + integrate + colliders) of the device-resident
+state; inputs are in HBM when the timed region starts.  Default workload: C3, the 16 M-particle
+dam break BASELINE.json's single-GPU target is quoted on; synthetic data.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from fluidsimulation_amd import native, scene  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# algorithmic bytes per fluid particle per launch of each stage.  sort is quoted
+# for the passes actually run: 4 + 16*passes for a fused-histogram sort, 20*passes for ours.
+ALG_BYTES = {"keys": 20, "table": 6, "reorder": 52, "density": 20, "force": 44, "integrate": 68}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", default="C3", choices=list(scene.CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-config", default=None,
+                    help="workload of the bounded CPU sample (default: same as --config)")
+    return ap.parse_args()
+
+
+def cpu_baseline(sc, name):
+    """The oracle (C restatement of the reference's Burst job path) timed on this host: one
+    FluidSPHByCPUSystem.OnUpdate of the same workload.  Reported, never the target."""
+    from oracle import oracle as O
+    O.build()
+    threads = min(O.max_threads(), 16)
+    t0 = time.perf_counter()
+    O.sph_step(sc.pos, sc.vel, sc.inv_mass, sc.params, sc.bpos, sc.bparams, sc.grid_size,
+               nthreads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": sc.n / dt, "unit": "particle-updates/s", "cores": threads, "kind": "port",
+            "sample": f"1 step of {name} ({sc.n} fluid + {sc.b} boundary particles), C restatement "
+                      f"of the reference's CPU path (serial map build + parallel-for jobs), "
+                      f"{dt:.2f} s"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    sc = scene.make_config(a.config, jittered=True)
+    p = native.make_params(sc.grid_size, body_bounds=(sc.tank_min, sc.tank_max))
+    ctx = native.Context(device=local, timings=True)
+    ctx.set_boundary(sc.bpos, sc.bparams)
+    ctx.set_colliders(sc.boxes)
+    ctx.upload(sc.pos, sc.vel, sc.inv_mass, sc.params, sc.grid_size)
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    ctx.step_resident(p, a.warmup)
+    barrier()
+    ctx.reset_timings()
+    t0 = time.perf_counter()
+    ctx.step_resident(p, a.steps)
+    ctx.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tm = ctx.timings()
+    pos, vel = ctx.download()
+    finite = bool(np.isfinite(pos).all() and np.isfinite(vel).all())
+
+    if rank == 0:
+        n = sc.n
+        ms_step = elapsed / a.steps * 1e3
+        stage_ms = {k: tm["ms"][k] / max(tm["steps"], 1) for k in tm["ms"]}
+        _, _, key_bits, _ = ctx.get_grid()
+        passes = (key_bits + 7) // 8
+        alg = dict(ALG_BYTES, sort=20 * passes)
+        dom = max((k for k in alg), key=lambda k: stage_ms[k])
+        achieved = alg[dom] * n / (stage_ms[dom] * 1e-3) / 1e9
+        step_alg = sum(alg.values())
+        out = {
+            "metric": "particle-updates/sec per SPH step", "value": world * n * a.steps / elapsed,
+            "unit": "particle-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.config} dam break: {n} fluid + {sc.b} boundary particles "
+                                   f"+ {len(sc.boxes)} box colliders per GPU, dt=1/60, h=1.0, "
+                                   f"jitter 0.02", "particles_per_gpu": n,
+                       "parallelism": "independent tanks, one per GPU" if world > 1 else "1 gpu"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "alg_bytes_per_particle": alg[dom],
+                         "avg_launch_ms": stage_ms[dom]},
+            "step_roofline": {"alg_bytes_per_particle_step": step_alg,
+                              "achieved_GBs": step_alg * n / (ms_step * 1e-3) / 1e9,
+                              "frac": step_alg * n / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "stage_ms": stage_ms, "finite": finite,
+        }
+        if not a.no_cpu_baseline:
+            bsc = sc if not a.cpu_baseline_config else scene.make_config(a.cpu_baseline_config)
+            out["cpu_baseline"] = cpu_baseline(bsc, a.cpu_baseline_config or a.config)
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -2,7 +2,7 @@
 # prints per-kernel VGPR / SGPR / scratch / LDS / occupancy of libsphfluid's kernels (gfx950)
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -fvisibility=hidden \
   -ffp-contract=off -fno-fast-math -Rpass-analysis=kernel-resource-usage \
-  "$(dirname "$0")/fluidsimulation_amd/csrc/sphfluid.hip" -o /tmp/_ru.so 2>&1 | python3 -c '
+  "$(dirname "$0")/../fluidsimulation_amd/csrc/sphfluid.hip" -o /tmp/_ru.so 2>&1 | python3 -c '
 import re,sys
 cur=None
 for line in sys.stdin:
