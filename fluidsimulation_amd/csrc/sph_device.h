@@ -14,12 +14,21 @@
 
 #define SPH_WAVE 64
 
-// Periodic cell table (see SphGrid in include/sphfluid.h)
+// Periodic cell table (see SphGrid in include/sphfluid.h).  Cells are grouped into tiles of
+// SPH_TX x SPH_TY x SPH_TZ cells; the dense key is  tile * SPH_TCELLS + local  with the tile index
+// x-fastest over tiles and the local index x-fastest inside the tile, so that after the sort the
+// particles of one tile are contiguous (one workgroup of the neighbour kernels = one tile) and
+// the x-runs of a tile are contiguous too.  gx, gy, gz are multiples of the tile dimensions.
+#define SPH_TX 4
+#define SPH_TY 4
+#define SPH_TZ 2
+#define SPH_TCELLS (SPH_TX * SPH_TY * SPH_TZ)
 struct GridDesc {
     int ox, oy, oz;
     int gx, gy, gz;
     float cellSize;
     int cells;
+    int ntx, nty, ntz, tiles;
 };
 
 // Per-material constants, computed once on the host in float32 in the reference's evaluation
@@ -75,12 +84,18 @@ __device__ __forceinline__ uint32_t fnv1_cell(int x, int y, int z)
     return hash;
 }
 
+// key of the cell with wrapped, origin-shifted coordinates 0 <= x < gx etc.
+__device__ __forceinline__ uint32_t tiled_key(int x, int y, int z, const GridDesc &g)
+{
+    const int tile = ((z / SPH_TZ) * g.nty + (y / SPH_TY)) * g.ntx + (x / SPH_TX);
+    const int local = ((z % SPH_TZ) * SPH_TY + (y % SPH_TY)) * SPH_TX + (x % SPH_TX);
+    return (uint32_t)(tile * SPH_TCELLS + local);
+}
+
 __device__ __forceinline__ uint32_t dense_key(int cx, int cy, int cz, const GridDesc &g)
 {
-    int x = wrap_cell(cx - g.ox, g.gx);
-    int y = wrap_cell(cy - g.oy, g.gy);
-    int z = wrap_cell(cz - g.oz, g.gz);
-    return (uint32_t)((z * g.gy + y) * g.gx + x);
+    return tiled_key(wrap_cell(cx - g.ox, g.gx), wrap_cell(cy - g.oy, g.gy),
+                     wrap_cell(cz - g.oz, g.gz), g);
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }

@@ -179,13 +179,21 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     }
 }
 
-// ClearTable + MapTable (FluidSolver.compute:85-112): the table is zeroed with a memset node,
-// then every run of equal keys writes its (start, end).
-__global__ void k_map_table(const uint32_t *__restrict__ skeys, int n, int2 *__restrict__ table)
+// ClearTable + MapTable (FluidSolver.compute:85-112): the tables are zeroed with memset nodes,
+// then every run of equal keys writes its (start, end); ttable does the same per tile
+// (tile = key / SPH_TCELLS) for the neighbour kernels' one-workgroup-per-tile launch.
+__global__ void k_map_table(const uint32_t *__restrict__ skeys, int n, int2 *__restrict__ table,
+                            int2 *__restrict__ ttable)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const uint32_t k = skeys[s];
-    if (s == 0 || k != skeys[s - 1]) table[k].x = s;
-    if (s == n - 1 || k != skeys[s + 1]) table[k].y = s + 1;
+    const uint32_t kp = s > 0 ? skeys[s - 1] : 0u, kn = s < n - 1 ? skeys[s + 1] : 0u;
+    if (s == 0 || k != kp) table[k].x = s;
+    if (s == n - 1 || k != kn) table[k].y = s + 1;
+    if (ttable) {
+        const uint32_t t = k / SPH_TCELLS;
+        if (s == 0 || t != kp / SPH_TCELLS) ttable[t].x = s;
+        if (s == n - 1 || t != kn / SPH_TCELLS) ttable[t].y = s + 1;
+    }
 }

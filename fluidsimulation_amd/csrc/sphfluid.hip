@@ -70,6 +70,7 @@ struct SphCtx {
     DevBuf<float> rho, prs;
     DevBuf<float4> force;
     DevBuf<int> dcount, fcount;
+    DevBuf<float4> zeros; // 16 zero records: source of the boundary's (v, q) in the force tile
     DevBuf<uint32_t> hashes, keysEcs;
     DevBuf<int> cells;
     DevBuf<float> io3a, io3b, io1;
@@ -90,7 +91,8 @@ struct SphCtx {
     // grid
     GridDesc grid{};
     bool gridExplicit = false, gridValid = false;
-    DevBuf<int2> table, btable;
+    DevBuf<int2> table, btable, ttable;
+    int fallbackCap = -1; // debug: LDS record cap override for the neighbour kernels
 
     // boundary
     int nb = 0;
@@ -297,9 +299,14 @@ void set_grid(SphCtx *c, const int origin[3], const int dims[3], float cellSize)
 {
     GridDesc g;
     g.ox = origin[0]; g.oy = origin[1]; g.oz = origin[2];
-    g.gx = dims[0]; g.gy = dims[1]; g.gz = dims[2];
+    // dimensions are rounded up to whole tiles
+    g.gx = (dims[0] + SPH_TX - 1) / SPH_TX * SPH_TX;
+    g.gy = (dims[1] + SPH_TY - 1) / SPH_TY * SPH_TY;
+    g.gz = (dims[2] + SPH_TZ - 1) / SPH_TZ * SPH_TZ;
     g.cellSize = cellSize;
-    g.cells = dims[0] * dims[1] * dims[2];
+    g.cells = g.gx * g.gy * g.gz;
+    g.ntx = g.gx / SPH_TX; g.nty = g.gy / SPH_TY; g.ntz = g.gz / SPH_TZ;
+    g.tiles = g.ntx * g.nty * g.ntz;
     const GridDesc &o = c->grid;
     if (!c->gridValid || o.ox != g.ox || o.oy != g.oy || o.oz != g.oz || o.gx != g.gx ||
         o.gy != g.gy || o.gz != g.gz || o.cellSize != g.cellSize)
@@ -364,9 +371,11 @@ int auto_grid(SphCtx *c, float cellSize)
         if (fits) return SPH_OK;
     }
     long long prod = 1;
+    const int tdim[3] = {SPH_TX, SPH_TY, SPH_TZ};
     for (int a = 0; a < 3; a++) {
         origin[a] = lo[a] - 2;
         long long d = (long long)hi[a] - lo[a] + 1 + 4;
+        d = (d + tdim[a] - 1) / tdim[a] * tdim[a];
         dims[a] = (int)std::min<long long>(std::max<long long>(d, 4), 1 << 20);
         prod *= dims[a];
     }
@@ -374,7 +383,7 @@ int auto_grid(SphCtx *c, float cellSize)
         int a = (dims[0] >= dims[1] && dims[0] >= dims[2]) ? 0 : (dims[1] >= dims[2] ? 1 : 2);
         if (dims[a] <= 4) break;
         prod /= dims[a];
-        dims[a] = std::max(4, dims[a] / 2);
+        dims[a] = std::max(4, (dims[a] / 2 + tdim[a] - 1) / tdim[a] * tdim[a]);
         prod *= dims[a];
     }
     set_grid(c, origin, dims, cellSize);
@@ -430,6 +439,10 @@ int ensure_fluid(SphCtx *c, int n)
     if (!rc) rc = ensure(c, c->rho, N);
     if (!rc) rc = ensure(c, c->prs, N);
     if (!rc) rc = ensure(c, c->force, N);
+    if (!rc && !c->zeros.p) {
+        rc = ensure(c, c->zeros, 16, false);
+        if (!rc) HIPCHK(c, hipMemsetAsync(c->zeros.p, 0, 16 * sizeof(float4), c->stream));
+    }
     return rc;
 }
 
@@ -470,7 +483,7 @@ int prepare_boundary(SphCtx *c)
         rc = radix_sort(c, c->bkeysA.p, c->bvalsA.p, c->bkeysB.p, c->bvalsB.p, B,
                         key_bits(c->grid.cells), &sk, &sv);
         if (rc) return rc;
-        k_map_table<<<blocks_for(B, 256), 256, 0, c->stream>>>(sk, B, c->btable.p);
+        k_map_table<<<blocks_for(B, 256), 256, 0, c->stream>>>(sk, B, c->btable.p, nullptr);
         k_gather4<<<blocks_for(B, 256), 256, 0, c->stream>>>(sv, B, c->bposmIn.p, c->bposm.p);
         c->bperm = sv;
         HIPCHK(c, hipGetLastError());
@@ -560,10 +573,10 @@ int sph_destroy(SphCtx *c)
         release(c->posm[i]); release(c->velq[i]); release(c->mat[i]); release(c->oid[i]);
     }
     release(c->keysA); release(c->keysB); release(c->valsA); release(c->valsB);
-    release(c->rho); release(c->prs); release(c->force); release(c->dcount); release(c->fcount);
+    release(c->rho); release(c->prs); release(c->force); release(c->zeros); release(c->dcount); release(c->fcount);
     release(c->hashes); release(c->keysEcs); release(c->cells);
     release(c->io3a); release(c->io3b); release(c->io1); release(c->ioU);
-    release(c->dmats); release(c->table); release(c->btable);
+    release(c->dmats); release(c->table); release(c->btable); release(c->ttable);
     release(c->bpos3); release(c->bpar3); release(c->bposmIn); release(c->bposm);
     release(c->bkeysA); release(c->bkeysB); release(c->bvalsA); release(c->bvalsB);
     release(c->boxState); release(c->devBoxes); release(c->bodyImpulse);
@@ -592,6 +605,7 @@ int sph_set_debug(SphCtx *c, int32_t flags)
 {
     if (!c) return SPH_E_INVALID;
     c->debug = flags;
+    c->fallbackCap = (flags & SPH_DEBUG_NO_LDS_TILE) ? 0 : -1;
     return SPH_OK;
 }
 
@@ -818,12 +832,15 @@ int sph_map_table(SphCtx *c)
     if (!c) return SPH_E_INVALID;
     if (!c->haveSort) return fail(c, SPH_E_INVALID, "sph_map_table before sph_radix_sort");
     int rc = ensure(c, c->table, (size_t)c->grid.cells);
+    if (!rc) rc = ensure(c, c->ttable, (size_t)c->grid.tiles);
     if (rc) return rc;
     rc = prepare_boundary(c);
     if (rc) return rc;
     StageTimer t(c, SPH_T_TABLE);
     HIPCHK(c, hipMemsetAsync(c->table.p, 0, (size_t)c->grid.cells * sizeof(int2), c->stream));
-    k_map_table<<<blocks_for(c->n, 256), 256, 0, c->stream>>>(c->sortedKeys, c->n, c->table.p);
+    HIPCHK(c, hipMemsetAsync(c->ttable.p, 0, (size_t)c->grid.tiles * sizeof(int2), c->stream));
+    k_map_table<<<blocks_for(c->n, 256), 256, 0, c->stream>>>(c->sortedKeys, c->n, c->table.p,
+                                                              c->ttable.p);
     HIPCHK(c, hipGetLastError());
     c->haveTable = true;
     c->ordered = false;
@@ -855,17 +872,18 @@ int sph_compute_density_and_pressure(SphCtx *c, const SphParams *p)
     rc = ensure_debug(c);
     if (rc) return rc;
     StageTimer t(c, SPH_T_DENSITY);
-    const int N = c->n, cur = c->cur;
+    const int cur = c->cur;
     const float4 *bp = c->nb > 0 ? c->bposm.p : nullptr;
     const int2 *bt = c->nb > 0 ? c->btable.p : nullptr;
+    const int cap = c->fallbackCap >= 0 ? std::min(c->fallbackCap, NB_DCAP) : NB_DCAP;
     if (c->debug & SPH_DEBUG_COUNTS)
-        k_density<true><<<blocks_for(N, 64), 64, 0, c->stream>>>(
-            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->sortedKeys, c->table.p, bp, bt,
-            c->grid, c->dmats.p, c->rho.p, c->prs.p, c->dcount.p, N);
+        k_density<true><<<c->grid.tiles, NB_THREADS, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->table.p, c->ttable.p, bp, bt,
+            c->grid, c->dmats.p, c->rho.p, c->prs.p, c->dcount.p, cap);
     else
-        k_density<false><<<blocks_for(N, 64), 64, 0, c->stream>>>(
-            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->sortedKeys, c->table.p, bp, bt,
-            c->grid, c->dmats.p, c->rho.p, c->prs.p, nullptr, N);
+        k_density<false><<<c->grid.tiles, NB_THREADS, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->table.p, c->ttable.p, bp, bt,
+            c->grid, c->dmats.p, c->rho.p, c->prs.p, nullptr, cap);
     HIPCHK(c, hipGetLastError());
     c->haveDensity = true;
     return SPH_OK;
@@ -877,19 +895,20 @@ int sph_compute_force(SphCtx *c, const SphParams *p)
     if (rc) return rc;
     if (!c->haveDensity) return fail(c, SPH_E_INVALID, "force before density");
     StageTimer t(c, SPH_T_FORCE);
-    const int N = c->n, cur = c->cur;
+    const int cur = c->cur;
     const float4 *bp = c->nb > 0 ? c->bposm.p : nullptr;
     const int2 *bt = c->nb > 0 ? c->btable.p : nullptr;
+    const int cap = c->fallbackCap >= 0 ? std::min(c->fallbackCap, NB_FCAP) : NB_FCAP;
     if (c->debug & SPH_DEBUG_COUNTS)
-        k_force<true><<<blocks_for(N, 64), 64, 0, c->stream>>>(
-            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->rho.p, c->prs.p, c->sortedKeys,
-            c->table.p, bp, bt, c->grid, c->dmats.p, p->gravity[0], p->gravity[1], p->gravity[2],
-            c->force.p, c->fcount.p, N);
+        k_force<true><<<c->grid.tiles, NB_THREADS, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->rho.p, c->prs.p, c->table.p,
+            c->ttable.p, bp, bt, c->grid, c->dmats.p, p->gravity[0], p->gravity[1], p->gravity[2],
+            c->force.p, c->fcount.p, cap, c->zeros.p);
     else
-        k_force<false><<<blocks_for(N, 64), 64, 0, c->stream>>>(
-            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->rho.p, c->prs.p, c->sortedKeys,
-            c->table.p, bp, bt, c->grid, c->dmats.p, p->gravity[0], p->gravity[1], p->gravity[2],
-            c->force.p, nullptr, N);
+        k_force<false><<<c->grid.tiles, NB_THREADS, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->rho.p, c->prs.p, c->table.p,
+            c->ttable.p, bp, bt, c->grid, c->dmats.p, p->gravity[0], p->gravity[1], p->gravity[2],
+            c->force.p, nullptr, cap, c->zeros.p);
     HIPCHK(c, hipGetLastError());
     c->haveForce = true;
     return SPH_OK;

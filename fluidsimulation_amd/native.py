@@ -24,7 +24,7 @@ STAGE_NAMES = ["keys", "sort", "table", "reorder", "density", "force", "integrat
  SPH_BUF_FORCE_COUNTS, SPH_BUF_POSITIONS, SPH_BUF_VELOCITIES, SPH_BUF_BOUNDARY_PERM,
  SPH_BUF_BOUNDARY_TABLE) = range(15)
 
-SPH_DEBUG_HASHES, SPH_DEBUG_COUNTS = 1, 2
+SPH_DEBUG_HASHES, SPH_DEBUG_COUNTS, SPH_DEBUG_NO_LDS_TILE = 1, 2, 4
 
 # every symbol include/sphfluid.h declares (tests check that the library exports them all)
 EXPORTS = [

@@ -93,8 +93,9 @@ typedef struct SphConfig {
 } SphConfig;
 
 /* Periodic cell table the dense sort key is built on (DESIGN.md "cell keys").  A particle in
- * quantised cell c (FluidSPHUtils.cs:236-243) gets key ((z*dims[1]+y)*dims[0]+x) with
- * (x,y,z) = (c - origin) mod dims. */
+ * quantised cell c (FluidSPHUtils.cs:236-243) has table coordinates (x,y,z) = (c - origin) mod
+ * dims; cells are grouped in tiles of 4 x 4 x 2 and key = tile * 32 + local, tiles x-fastest over
+ * the table, cells x-fastest inside a tile.  dims are rounded up to whole tiles. */
 typedef struct SphGrid {
     int32_t origin[3];
     int32_t dims[3];
@@ -138,7 +139,9 @@ typedef struct SphCtx SphCtx;
 /* debug flags for sph_set_debug: extra parity outputs, off in production */
 enum {
     SPH_DEBUG_HASHES = 1, /* hash_position also writes SPH_BUF_HASHES / SPH_BUF_CELLS        */
-    SPH_DEBUG_COUNTS = 2  /* density / force kernels also write the neighbour-count buffers  */
+    SPH_DEBUG_COUNTS = 2, /* density / force kernels also write the neighbour-count buffers  */
+    SPH_DEBUG_NO_LDS_TILE = 4 /* neighbour kernels take their global-memory path for every
+                                 tile (the path used when a tile's halo overflows the LDS)  */
 };
 
 /* ---- life cycle --------------------------------------------------------------------------

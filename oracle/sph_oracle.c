@@ -438,7 +438,8 @@ ORC_API void orc_cell_table(const uint32_t *sorted_keys, int n, int32_t *table, 
 }
 
 /* Build-defined dense key (DESIGN.md "cell keys"): the quantised cell, shifted by an origin cell
- * and wrapped into a dims[0] x dims[1] x dims[2] periodic table, x fastest. */
+ * and wrapped into a dims[0] x dims[1] x dims[2] periodic table (dims are multiples of the tile
+ * 4 x 4 x 2); key = tile * 32 + local, tiles x-fastest over the table, cells x-fastest in a tile. */
 static inline int32_t wrap1(int32_t c, int32_t g)
 {
     int32_t m = c % g;
@@ -447,11 +448,15 @@ static inline int32_t wrap1(int32_t c, int32_t g)
 ORC_API void orc_dense_keys(const int32_t *cells, int n, const int32_t *origin,
                             const int32_t *dims, uint32_t *keys)
 {
+    const int TX = 4, TY = 4, TZ = 2;
+    const int ntx = dims[0] / TX, nty = dims[1] / TY;
     for (int i = 0; i < n; i++) {
         int32_t x = wrap1(cells[3 * i] - origin[0], dims[0]);
         int32_t y = wrap1(cells[3 * i + 1] - origin[1], dims[1]);
         int32_t z = wrap1(cells[3 * i + 2] - origin[2], dims[2]);
-        keys[i] = (uint32_t)((z * dims[1] + y) * dims[0] + x);
+        int32_t tile = ((z / TZ) * nty + (y / TY)) * ntx + (x / TX);
+        int32_t local = ((z % TZ) * TY + (y % TY)) * TX + (x % TX);
+        keys[i] = (uint32_t)(tile * (TX * TY * TZ) + local);
     }
 }
 

@@ -85,17 +85,25 @@ def test_sort_table_reorder(ctx, oracle, which):
                                   oracle.cell_table(bsorted, ncells))
 
 
+# debug flag sets: parity outputs on (exact-predicate kernels), production kernels (branch-free),
+# and the global-memory path the kernels take when a tile's halo overflows the LDS tile
+_ALL = native.SPH_DEBUG_HASHES | native.SPH_DEBUG_COUNTS
+_FLAGS = [_ALL, 0, _ALL | native.SPH_DEBUG_NO_LDS_TILE, native.SPH_DEBUG_NO_LDS_TILE]
+
+
+@pytest.mark.parametrize("flags", _FLAGS)
 @pytest.mark.parametrize("which", [0, 1])
-def test_density_pressure_force(ctx, oracle, which):
+def test_density_pressure_force(ctx, oracle, which, flags):
     sc = list(_scenes())[which]
     if which == 1:
         rng = np.random.default_rng(7)
         sc.vel = rng.normal(0, 1.0, sc.pos.shape).astype(np.float32)
-    p = load_scene(ctx, sc)
+    p = load_scene(ctx, sc, debug=flags)
     run_to_force(ctx, p)
     dens, pres, cnt = oracle.density_pressure(sc.pos, sc.inv_mass, sc.params, sc.bpos,
                                               sc.grid_size)
-    np.testing.assert_array_equal(ctx.read(native.SPH_BUF_DENSITY_COUNTS), cnt)
+    if flags & native.SPH_DEBUG_COUNTS:
+        np.testing.assert_array_equal(ctx.read(native.SPH_BUF_DENSITY_COUNTS), cnt)
     gd = ctx.read(native.SPH_BUF_DENSITIES)
     gp = ctx.read(native.SPH_BUF_PRESSURES)
     assert_close(gd, dens, what="density")
@@ -103,7 +111,8 @@ def test_density_pressure_force(ctx, oracle, which):
     # force parity is checked on the oracle's own densities AND end to end
     forces, fcnt = oracle.force(sc.pos, sc.inv_mass, sc.vel, sc.params, sc.bpos, sc.bparams,
                                 dens, pres, sc.grid_size)
-    np.testing.assert_array_equal(ctx.read(native.SPH_BUF_FORCE_COUNTS), fcnt)
+    if flags & native.SPH_DEBUG_COUNTS:
+        np.testing.assert_array_equal(ctx.read(native.SPH_BUF_FORCE_COUNTS), fcnt)
     assert_close(ctx.read(native.SPH_BUF_FORCES), forces, rtol=2e-5, what="force")
 
 
