@@ -6,20 +6,23 @@
 // per thread and gather every neighbour from global memory.
 //
 // Mapping (DESIGN.md "neighbour kernels").  One 256-thread workgroup owns one TILE of 4x4x2
-// cells (the sort key groups particles by tile, sph_device.h):
-//   1. threads 0..143 look up the (start,end) of the 6x6x4 halo of cells around the tile in the
-//      fluid and boundary tables; a block scan turns the counts into LDS offsets;
-//   2. the four waves copy the halo's particles into the LDS tile with coalesced 16-byte loads,
-//      cell by cell, x-runs contiguous: each particle is read from L2/HBM ~4.5 times per pass
-//      instead of 27 times;
-//   3. each wave takes 8 cells of the tile.  For a cell with T particles (the targets) the 64
-//      lanes split as T targets x S = 64/T candidate slices; a lane keeps its target in VGPRs
-//      (every inner-loop operand is a VGPR: VALU ops with an SGPR or constant operand issue at
-//      half rate on gfx950, tools/microbench_valu.hip) and walks the 9 LDS row windows
-//      (x-1..x+1 of one (y,z)) with stride S; one ds_read_b128 feeds S candidates to T lanes;
+// cells (the sort key groups particles by tile, sph_device.h) and works through it in BLOCKS:
+// the whole tile when its halo fits the LDS tile, else its eight 2x2x1 sub-blocks, else single
+// cells (the fluid compresses several-fold at the bottom of a deep tank), else -- for a cell whose
+// 27-cell neighbourhood still overflows -- the same walk straight from global memory.  Per block:
+//   1. one thread per cell of the block's halo (block + one cell on every side) turns the table
+//      entries fetched at kernel start into LDS offsets with a block scan;
+//   2. the halo's particles are copied into the LDS tile by LDS-DMA (global_load_lds_dwordx4: no
+//      VGPR staging, 64 records per wave-instruction), fluid then boundary per cell, x-runs
+//      contiguous; a particle is read from L2/HBM ~4.5 times per pass instead of 27 times; the
+//      per-target constants of the block's own particles are cached in LDS at the same time, so
+//      the compute phase touches no global memory until its stores;
+//   3. the block's cells are dealt to the four waves.  For a cell with T particles (the targets)
+//      the 64 lanes split as T targets x S = 64/T candidate slices; a lane keeps its target in
+//      VGPRs (every inner-loop operand is a VGPR: VALU ops with an SGPR or constant operand issue
+//      at about half rate on gfx950, tools/microbench_valu.hip) and walks the 9 LDS row windows
+//      (x-1..x+1 of one (y,z)) with stride S, four ds_read_b128 issued ahead of their use;
 //   4. per-target partial sums are folded over the S slices through a wave-private LDS strip.
-// A tile whose halo does not fit the LDS tile (pile-ups) takes the same walk straight from
-// global memory (tile_fallback), so any particle distribution is handled.
 //
 // Arithmetic.  The production kernels are branch-free: density uses w/h2 = clamp(1 - d2/h2),
 // force uses (h-r)/h = clamp(1 - r/h), so candidates outside the support contribute exactly 0
@@ -38,22 +41,41 @@
 #define NB_HCELLS (NB_HX * NB_HY * NB_HZ) // 144
 #define NB_THREADS 256
 #define NB_WAVES 4
-#define NB_CELLS_PER_WAVE (SPH_TCELLS / NB_WAVES)
-#define NB_DCAP 2048 // LDS records per tile, density kernel (32 KB)
-#define NB_FCAP 1792 // LDS records per tile, force kernel (2 x 28 KB)
-#define NB_TCAP 512  // tile's own particles whose constants are cached in LDS
-#define NB_NQ 4      // candidate slots per row window issued back to back
+#define NB_DCAP 2048 // LDS records per block, density kernel (32 KB)
+#define NB_FCAP 1792 // LDS records per block, force kernel (2 x 28 KB)
+#define NB_TCAP 512  // targets per block whose constants are cached in LDS
 
 struct TileShared {
-    int fs[NB_HCELLS];       // fluid start (global sorted index) of the halo cell
-    int fc[NB_HCELLS];       // fluid count
-    int bs[NB_HCELLS];       // boundary start
-    int bc[NB_HCELLS];       // boundary count
-    int pref[NB_HCELLS + 1]; // LDS offset of the halo cell's records (fluid first, then boundary)
-    int scan[NB_WAVES];
+    int fs[NB_HCELLS];        // tile halo: fluid start (global sorted index) of the cell
+    int fc[NB_HCELLS];        //            fluid count
+    int bs[NB_HCELLS];        //            boundary start
+    int bc[NB_HCELLS];        //            boundary count
+    int hmap[NB_HCELLS];      // block halo cell -> tile halo cell
+    int spref[NB_HCELLS + 1]; // LDS offset of the block halo cell's records (fluid, then boundary)
+    int tpref[SPH_TCELLS + 1]; // ordinal of the first target of every cell of the block
+    int scan[2 * NB_WAVES];
     float red[NB_WAVES][4][64];
-    float4 tconst[NB_TCAP];  // per-target constants of the tile's own particles
-    float tthr[NB_TCAP];     // COUNT variants: the exact predicate threshold (h2 / thrF)
+    float4 tconst[NB_TCAP];   // per-target constants of the block's own particles
+    float tthr[NB_TCAP];      // COUNT variants: the exact predicate threshold (h2 / thrF)
+};
+
+// kernel arguments shared by both passes
+struct NbArgs {
+    const float4 *posm;
+    float4 *velq;
+    const uint32_t *mat;
+    const float *rhoIn;
+    const float *prsIn;
+    const int2 *table, *ttable, *btable;
+    const float4 *bposm;
+    const Mat *mats;
+    const float4 *zeros;
+    float *rho, *prs;
+    float4 *force;
+    int *counts;
+    GridDesc g;
+    float gx, gy, gz;
+    int cap;
 };
 
 __device__ __forceinline__ int wrapi(int c, int g) { return c < 0 ? c + g : (c >= g ? c - g : c); }
@@ -63,6 +85,11 @@ __device__ __forceinline__ void split_lane(int lane, int S, int &u, int &slice)
 {
     u = (int)(((float)lane + 0.5f) * (1.0f / (float)S)); // exact for lane < 64
     slice = lane - u * S;
+}
+// S = floor(64 / T) without an integer division
+__device__ __forceinline__ int slices_for(int T)
+{
+    return (int)(64.5f * __builtin_amdgcn_rcpf((float)T));
 }
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -74,63 +101,69 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// step 1: halo table look-ups + offsets.  Returns the number of records the halo holds.
-__device__ __forceinline__ int tile_setup(TileShared &sh, int tile, const GridDesc &g,
-                                          const int2 *__restrict__ table,
-                                          const int2 *__restrict__ btable)
+// last index i in [0, n) with a[i] <= q (a non-decreasing, a[0] <= q)
+__device__ __forceinline__ int bisect_le(const int *a, int n, int q)
 {
+    int lo = 0, hi = n - 1;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// exclusive scan of two values per thread over the 256-thread block
+__device__ __forceinline__ void block_scan2(TileShared &sh, int a, int b, int &ea, int &eb,
+                                            int &ta, int &tb)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int xa = __shfl_up(ia, d, 64), xb = __shfl_up(ib, d, 64);
+        if (lane >= d) { ia += xa; ib += xb; }
+    }
+    __syncthreads(); // previous users of sh.scan are done
+    if (lane == 63) { sh.scan[2 * w] = ia; sh.scan[2 * w + 1] = ib; }
+    __syncthreads();
+    int ba = 0, bb = 0;
+    ta = 0; tb = 0;
+#pragma unroll
+    for (int i = 0; i < NB_WAVES; i++) {
+        const int xa = sh.scan[2 * i], xb = sh.scan[2 * i + 1];
+        if (i < w) { ba += xa; bb += xb; }
+        ta += xa; tb += xb;
+    }
+    ea = ba + ia - a;
+    eb = bb + ib - b;
+}
+
+// table look-ups for the 6x6x4 halo of the tile (once per workgroup)
+__device__ __forceinline__ void tile_lookup(TileShared &sh, int tile, const NbArgs &A)
+{
+    const GridDesc &g = A.g;
     const int tid = threadIdx.x;
-    const int tx = tile % g.ntx, t2 = tile / g.ntx, ty = t2 % g.nty, tz = t2 / g.nty;
-    int cnt = 0;
     if (tid < NB_HCELLS) {
+        const int tx = tile % g.ntx, t2 = tile / g.ntx, ty = t2 % g.nty, tz = t2 / g.nty;
         const int hx = tid % NB_HX, hy = (tid / NB_HX) % NB_HY, hz = tid / (NB_HX * NB_HY);
         const int x = wrapi(tx * SPH_TX + hx - 1, g.gx), y = wrapi(ty * SPH_TY + hy - 1, g.gy),
                   z = wrapi(tz * SPH_TZ + hz - 1, g.gz);
         const uint32_t k = tiled_key(x, y, z, g);
-        const int2 f = table[k];
+        const int2 f = A.table[k];
         int2 b = make_int2(0, 0);
-        if (btable) b = btable[k];
+        if (A.btable) b = A.btable[k];
         sh.fs[tid] = f.x;
         sh.fc[tid] = f.y - f.x;
         sh.bs[tid] = b.x;
         sh.bc[tid] = b.y - b.x;
-        cnt = (f.y - f.x) + (b.y - b.x);
     }
-    // block exclusive scan
-    const int lane = tid & 63, w = tid >> 6;
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += t;
-    }
-    if (lane == 63) sh.scan[w] = incl;
     __syncthreads();
-    int basew = 0, total = 0;
-#pragma unroll
-    for (int i = 0; i < NB_WAVES; i++) {
-        const int t = sh.scan[i];
-        if (i < w) basew += t;
-        total += t;
-    }
-    if (tid < NB_HCELLS) sh.pref[tid] = basew + incl - cnt;
-    if (tid == NB_HCELLS) sh.pref[NB_HCELLS] = total;
-    __syncthreads();
-    return total;
 }
 
-// step 2: copy the halo's particles into LDS.  One thread per record; the owning halo cell is
-// found by bisection over the 145 offsets, so all loads of a thread are independent and the
-// compiler can keep several in flight.
-__device__ __forceinline__ int tile_locate(const TileShared &sh, int q)
+__device__ __forceinline__ int tile_halo_index(int x, int y, int z) // tile-local cell + 1
 {
-    int lo = 0, hi = NB_HCELLS - 1; // last halo cell whose offset is <= q
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (sh.pref[mid] <= q) lo = mid; else hi = mid - 1;
-    }
-    return lo;
+    return (z * NB_HY + y) * NB_HX + x;
 }
 
 // LDS-DMA: global_load_lds_dwordx4 writes 16 bytes per lane to  M0 base + lane*16  with no VGPR
@@ -138,47 +171,12 @@ __device__ __forceinline__ int tile_locate(const TileShared &sh, int q)
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <bool WITH_V>
-__device__ __forceinline__ void tile_stage(const TileShared &sh, int total, float4 *recP,
-                                           float4 *recV, const float4 *__restrict__ posm,
-                                           const float4 *__restrict__ velq,
-                                           const float4 *__restrict__ bposm,
-                                           const float4 *__restrict__ zeros)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int q0 = 0; q0 < total; q0 += NB_THREADS) {
-        const int qw = q0 + w * 64; // first record of this wave-instruction (wave-uniform)
-        const int q = qw + lane;
-        if (q < total) {
-            const int h = tile_locate(sh, q);
-            const int k = q - sh.pref[h], fc = sh.fc[h];
-            const float4 *gp, *gv;
-            if (k < fc) {
-                gp = posm + (sh.fs[h] + k);
-                gv = velq + (sh.fs[h] + k);
-            } else {
-                gp = bposm + (sh.bs[h] + (k - fc));
-                gv = zeros; // boundary: v = 0, q = 0
-            }
-            __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(recP + qw), 16, 0, 0);
-            if (WITH_V) __builtin_amdgcn_global_load_lds((gptr_t)gv, (lptr_t)(recV + qw), 16, 0, 0);
-        }
-    }
-}
-
-// halo index of the centre cell `lc` (0..31) of the tile and of the first cell of its row window
-__device__ __forceinline__ int halo_center(int lc)
-{
-    const int lx = lc % SPH_TX, ly = (lc / SPH_TX) % SPH_TY, lz = lc / (SPH_TX * SPH_TY);
-    return ((lz + 1) * NB_HY + (ly + 1)) * NB_HX + (lx + 1);
-}
-__device__ __forceinline__ int halo_row(int hc, int r) // r = 0..8 -> (dy, dz); returns hx-1 cell
-{
-    return hc + ((r / 3) - 1) * (NB_HX * NB_HY) + ((r % 3) - 1) * NB_HX - 1;
-}
+// keeps all four components of an LDS record live so that the read is one ds_read_b128
+// (4 LDS cycles per wave) and not a ds_read_b96 (8 cycles)
+__device__ __forceinline__ void keep_b128(const float4 &c) { asm volatile("" ::"v"(c.w)); }
 
 // ------------------------------------------------------------------------------------------
-// per-pair arithmetic shared by the LDS walk and the global-memory fallback
+// per-pair arithmetic
 
 struct DensityTarget {
     float x, y, z, h2, negInvH2;
@@ -203,8 +201,8 @@ __device__ __forceinline__ void density_pair(const DensityTarget &t, const float
 
 struct ForceTarget {
     float x, y, z, vx, vy, vz;
-    float Pi;       // p_i / rho_i^2
-    float h, negInvH, thrF;
+    float Pi; // p_i / rho_i^2
+    float negInvH, thrF;
 };
 struct ForceAcc {
     float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
@@ -229,8 +227,8 @@ __device__ __forceinline__ void force_pair(const ForceTarget &t, const float4 &c
     const float rinv = fminf(__builtin_amdgcn_rsqf(d2), 1.0e18f);
     const float r = d2 * rinv;
     const float tt = __builtin_amdgcn_fmed3f(__builtin_fmaf(r, t.negInvH, 1.0f), 0.f, 1.0f);
-    const float mt = cp.w * tt;                        // m_j t
-    const float ap = mt * tt * (t.Pi + cv.w) * rinv;   // m_j t^2 (P_i + q_j) / r
+    const float mt = cp.w * tt;                      // m_j t
+    const float ap = mt * tt * (t.Pi + cv.w) * rinv; // m_j t^2 (P_i + q_j) / r
     a.px = __builtin_fmaf(ap, dx, a.px);
     a.py = __builtin_fmaf(ap, dy, a.py);
     a.pz = __builtin_fmaf(ap, dz, a.pz);
@@ -239,344 +237,323 @@ __device__ __forceinline__ void force_pair(const ForceTarget &t, const float4 &c
     a.vz = __builtin_fmaf(mt, cv.z - t.vz, a.vz);
 }
 
-// ------------------------------------------------------------------------------------------
-// wave-level pieces of the LDS walk
+// per-target accumulators / finalisation, one type per pass -------------------------------------
+template <bool FORCE, bool COUNT> struct Pass;
 
-// (T targets) x (S slices): S = floor(64 / T) without an integer division
-__device__ __forceinline__ int slices_for(int T)
-{
-    return (int)(64.5f * __builtin_amdgcn_rcpf((float)T));
-}
+template <bool COUNT> struct Pass<false, COUNT> {
+    DensityTarget t;
+    float acc = 0.f;
+    int cnt = 0;
+    float4 tc; // -1/h2, scale, k, rho0
+    __device__ __forceinline__ void pair(const float4 &cp, const float4 &, bool)
+    {
+        density_pair<COUNT>(t, cp, acc, cnt);
+    }
+    // folds the slices and writes rho, p, q for target ti
+    __device__ __forceinline__ void finish(TileShared &sh, const NbArgs &A, int w, int lane, int S,
+                                           bool writer, int ti)
+    {
+        float *red = sh.red[w][0];
+        int *redc = (int *)sh.red[w][1];
+        wave_lds_fence();
+        red[lane] = acc;
+        if (COUNT) redc[lane] = cnt;
+        wave_lds_fence();
+        if (writer) {
+            float sum = 0.f;
+            int c2 = 0;
+            for (int q = 0; q < S; q++) {
+                sum += red[lane + q];
+                if (COUNT) c2 += redc[lane + q];
+            }
+            // rho_i = m_i*315/(64*pi*h^9) * sum (h2-d2)^3 ; p_i = max(k (rho_i - rho0), 0)
+            const float density = tc.y * sum;
+            const float pressure = fmaxf(tc.z * (density - tc.w), 0.f);
+            A.rho[ti] = density;
+            A.prs[ti] = pressure;
+            A.velq[ti].w = pressure / (density * density);
+            if (COUNT) A.counts[ti] = c2;
+        }
+    }
+};
 
-// lanes 0..8 fetch the LDS window [rs, re) of the nine (dy,dz) rows of the cell with halo index hc
-__device__ __forceinline__ void row_windows(const TileShared &sh, int hc, int lane, int &rs,
-                                            int &re)
+template <bool COUNT> struct Pass<true, COUNT> {
+    ForceTarget t;
+    ForceAcc a;
+    float4 tc; // -1/h, Cp, Cv, rho
+    __device__ __forceinline__ void pair(const float4 &cp, const float4 &cv, bool notSelf)
+    {
+        force_pair<COUNT>(t, cp, cv, notSelf, a);
+    }
+    __device__ __forceinline__ void finish(TileShared &sh, const NbArgs &A, int w, int lane, int S,
+                                           bool writer, int ti)
+    {
+        float *redx = sh.red[w][0], *redy = sh.red[w][1], *redz = sh.red[w][2];
+        int *redc = (int *)sh.red[w][3];
+        wave_lds_fence();
+        redx[lane] = tc.y * a.px + tc.z * a.vx;
+        redy[lane] = tc.y * a.py + tc.z * a.vy;
+        redz[lane] = tc.y * a.pz + tc.z * a.vz;
+        if (COUNT) redc[lane] = a.cnt;
+        wave_lds_fence();
+        if (writer) {
+            float fx = 0.f, fy = 0.f, fz = 0.f;
+            int c2 = 0;
+            for (int q = 0; q < S; q++) {
+                fx += redx[lane + q];
+                fy += redy[lane + q];
+                fz += redz[lane + q];
+                if (COUNT) c2 += redc[lane + q];
+            }
+            // forces = forcePressure + forceViscosity + gravity * rho_i  (:140,:202)
+            const float trho = tc.w;
+            A.force[ti] =
+                make_float4(fx + A.gx * trho, fy + A.gy * trho, fz + A.gz * trho, 0.f);
+            if (COUNT) A.counts[ti] = c2;
+        }
+    }
+};
+
+// constants of one target from its material (and, for the force pass, its density)
+template <bool FORCE, bool COUNT>
+__device__ __forceinline__ void target_constants(const NbArgs &A, int gi, float4 &tc, float &thr)
 {
-    rs = 0;
-    re = 0;
-    if (lane < 9) {
-        const int h0 = hc + ((lane / 3) - 1) * (NB_HX * NB_HY) + ((lane % 3) - 1) * NB_HX - 1;
-        rs = sh.pref[h0];
-        re = sh.pref[h0 + 3];
+    const Mat m = A.mats[A.mat[gi]];
+    if (FORCE) {
+        const float d = A.rhoIn[gi];
+        // -1/h, rho_i*45/(pi h^6)*h^2, mu_i/rho_i*45/(pi h^6)*h, rho_i
+        tc = make_float4(-1.0f / m.h, d * m.spiky * (m.h * m.h), m.viscosity / d * m.spiky * m.h, d);
+        thr = m.thrF;
+    } else {
+        const float scale = COUNT ? m.poly6 : m.poly6 * (m.h2 * m.h2 * m.h2);
+        tc = make_float4(-1.0f / m.h2, scale, m.gasConstant, m.restDensity);
+        thr = m.h2;
     }
 }
 
-// keeps all four components of an LDS record live so that the read is one ds_read_b128
-// (4 LDS cycles per wave) and not a ds_read_b96 (8 cycles)
-__device__ __forceinline__ void keep_b128(const float4 &c) { asm volatile("" ::"v"(c.w)); }
-
 // ------------------------------------------------------------------------------------------
-// density + pressure
-template <bool COUNT>
-__global__ __launch_bounds__(NB_THREADS) void k_density(
-    const float4 *__restrict__ posm, float4 *__restrict__ velq, const uint32_t *__restrict__ mat,
-    const int2 *__restrict__ table, const int2 *__restrict__ ttable,
-    const float4 *__restrict__ bposm, const int2 *__restrict__ btable, GridDesc g,
-    const Mat *__restrict__ mats, float *__restrict__ rho, float *__restrict__ prs,
-    int *__restrict__ counts, int cap)
+// one block (bx0.., sx x sy x sz cells, tile-local) through the LDS tile.  Returns false, having
+// done nothing, when the block's halo or its targets do not fit.
+template <bool FORCE, bool COUNT>
+__device__ bool process_block(TileShared &sh, float4 *recP, float4 *recV, const NbArgs &A,
+                              int bx0, int by0, int bz0, int sx, int sy, int sz)
 {
-    __shared__ TileShared sh;
-    __shared__ float4 recP[NB_DCAP + 1]; // + the FAR record that padding lanes read
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int hxN = sx + 2, hyN = sy + 2, nh = hxN * hyN * (sz + 2), ncells = sx * sy * sz;
+    const int cap = A.cap;
 
-    const int tile = blockIdx.x;
-    const int2 trange = ttable[tile];
-    if (trange.y <= trange.x) return; // no fluid particle in this tile
-    const int ntile = trange.y - trange.x;
-    const int total = tile_setup(sh, tile, g, table, btable);
-    const bool inLds = total <= cap && ntile <= NB_TCAP;
-    if (inLds) {
-        tile_stage<false>(sh, total, recP, nullptr, posm, nullptr, bposm, nullptr);
-        // constants of the tile's own particles: -1/h2, scale, k, rho0
-        for (int i = threadIdx.x; i < ntile; i += NB_THREADS) {
-            const Mat m = mats[mat[trange.x + i]];
-            const float scale = COUNT ? m.poly6 : m.poly6 * (m.h2 * m.h2 * m.h2);
-            sh.tconst[i] = make_float4(-1.0f / m.h2, scale, m.gasConstant, m.restDensity);
-            if (COUNT) sh.tthr[i] = m.h2;
+    // 1. offsets
+    int cnt = 0, tcnt = 0;
+    if (tid < nh) {
+        const int hx = tid % hxN, hy = (tid / hxN) % hyN, hz = tid / (hxN * hyN);
+        const int f = tile_halo_index(bx0 + hx, by0 + hy, bz0 + hz);
+        sh.hmap[tid] = f;
+        cnt = sh.fc[f] + sh.bc[f];
+    }
+    if (tid < ncells) {
+        const int cx = tid % sx, cy = (tid / sx) % sy, cz = tid / (sx * sy);
+        tcnt = sh.fc[tile_halo_index(bx0 + cx + 1, by0 + cy + 1, bz0 + cz + 1)];
+    }
+    int e1, e2, total, ttotal;
+    block_scan2(sh, cnt, tcnt, e1, e2, total, ttotal);
+    if (total > cap || ttotal > NB_TCAP) return false;
+    if (ttotal == 0) return true;
+    if (tid < nh) sh.spref[tid] = e1;
+    if (tid == nh) sh.spref[nh] = total;
+    if (tid < ncells) sh.tpref[tid] = e2;
+    if (tid == ncells) sh.tpref[ncells] = ttotal;
+    __syncthreads();
+
+    // 2. stage records (LDS-DMA) and target constants
+    for (int q0 = 0; q0 < total; q0 += NB_THREADS) {
+        const int qw = q0 + w * 64; // first record of this wave-instruction (wave-uniform)
+        const int q = qw + lane;
+        if (q < total) {
+            const int hcell = bisect_le(sh.spref, nh, q);
+            const int f = sh.hmap[hcell];
+            const int k = q - sh.spref[hcell], fc = sh.fc[f];
+            const float4 *gp, *gv;
+            if (k < fc) {
+                gp = A.posm + (sh.fs[f] + k);
+                gv = A.velq + (sh.fs[f] + k);
+            } else {
+                gp = A.bposm + (sh.bs[f] + (k - fc));
+                gv = A.zeros; // boundary: v = 0, q = 0
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(recP + qw), 16, 0, 0);
+            if (FORCE) __builtin_amdgcn_global_load_lds((gptr_t)gv, (lptr_t)(recV + qw), 16, 0, 0);
         }
-        if (threadIdx.x == 0) recP[NB_DCAP] = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f);
+    }
+    for (int i = tid; i < ttotal; i += NB_THREADS) {
+        const int c = bisect_le(sh.tpref, ncells, i);
+        const int cx = c % sx, cy = (c / sx) % sy, cz = c / (sx * sy);
+        const int f = tile_halo_index(bx0 + cx + 1, by0 + cy + 1, bz0 + cz + 1);
+        float4 tc;
+        float thr;
+        target_constants<FORCE, COUNT>(A, sh.fs[f] + (i - sh.tpref[c]), tc, thr);
+        sh.tconst[i] = tc;
+        if (COUNT) sh.tthr[i] = thr;
+    }
+    if (tid == 0) {
+        recP[cap] = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f); // what padding lanes read
+        if (FORCE) recV[cap] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float *red = sh.red[w][0];
-    int *redc = (int *)sh.red[w][1];
-    for (int ci = 0; ci < NB_CELLS_PER_WAVE; ci++) {
-        const int hc = halo_center(w * NB_CELLS_PER_WAVE + ci);
-        const int ncell = uniform_i(sh.fc[hc]);
-        const int cstart = uniform_i(sh.fs[hc]);
+    // 3. units = (cell, part); a part is a contiguous share of the cell's targets
+    const int P = ncells >= NB_WAVES ? 1 : NB_WAVES / ncells;
+    for (int unit = w; unit < ncells * P; unit += NB_WAVES) {
+        const int c = unit / P, part = unit - c * P;
+        const int cx = c % sx, cy = (c / sx) % sy, cz = c / (sx * sy);
+        const int f = tile_halo_index(bx0 + cx + 1, by0 + cy + 1, bz0 + cz + 1);
+        const int ncell = uniform_i(sh.fc[f]);
         if (ncell == 0) continue;
-        if (inLds) {
-            const int clds = uniform_i(sh.pref[hc]);
-            int rs, re;
-            row_windows(sh, hc, lane, rs, re);
-            for (int tb = 0; tb < ncell; tb += 64) {
-                const int T = min(64, ncell - tb);
-                const int S = slices_for(T);
-                int u, slice;
-                split_lane(lane, S, u, slice);
-                const bool active = u < T;
-                const int tloc = tb + (active ? u : 0);
-                const float4 tp = recP[clds + tloc];
-                const float4 tc = sh.tconst[cstart - trange.x + tloc];
-                DensityTarget t;
-                t.x = tp.x; t.y = tp.y; t.z = tp.z;
-                t.negInvH2 = tc.x;
-                t.h2 = COUNT ? sh.tthr[cstart - trange.x + tloc] : 0.f;
-                float acc = 0.f;
-                int cnt = 0;
-#pragma unroll
-                for (int r = 0; r < 9; r++) {
-                    const int s0 = bcast_i(rs, r), e0 = bcast_i(re, r);
-                    float4 c[NB_NQ];
-#pragma unroll
-                    for (int q = 0; q < NB_NQ; q++) {
-                        const int k = s0 + q * S + slice;
-                        c[q] = recP[k < e0 ? k : NB_DCAP];
-                        keep_b128(c[q]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < NB_NQ; q++) density_pair<COUNT>(t, c[q], acc, cnt);
-                    for (int k0 = s0 + NB_NQ * S; k0 < e0; k0 += S) { // long windows
-                        const int k = k0 + slice;
-                        const float4 cd = recP[k < e0 ? k : NB_DCAP];
-                        density_pair<COUNT>(t, cd, acc, cnt);
-                    }
-                }
-                // fold the S slices of every target (wave-private strip)
-                wave_lds_fence();
-                red[lane] = acc;
-                if (COUNT) redc[lane] = cnt;
-                wave_lds_fence();
-                if (active && slice == 0) {
-                    float sum = 0.f;
-                    int c2 = 0;
-                    for (int q = 0; q < S; q++) {
-                        sum += red[lane + q];
-                        if (COUNT) c2 += redc[lane + q];
-                    }
-                    // rho_i = m_i*315/(64*pi*h^9) * sum (h2-d2)^3 ; p_i = max(k (rho_i - rho0), 0)
-                    const float density = tc.y * sum;
-                    const float pressure = fmaxf(tc.z * (density - tc.w), 0.f);
-                    const int ti = cstart + tloc;
-                    rho[ti] = density;
-                    prs[ti] = pressure;
-                    velq[ti].w = pressure / (density * density);
-                    if (COUNT) counts[ti] = c2;
-                }
-            }
-        } else {
-            // global-memory walk (halo does not fit the LDS tile)
-            for (int tb = 0; tb < ncell; tb += 64) {
-                const int T = min(64, ncell - tb);
-                const int S = slices_for(T);
-                int u, slice;
-                split_lane(lane, S, u, slice);
-                const bool active = u < T;
-                const int ti = cstart + tb + (active ? u : 0);
-                const float4 tp = posm[ti];
-                const Mat m = mats[mat[ti]];
-                DensityTarget t;
-                t.x = tp.x; t.y = tp.y; t.z = tp.z;
-                t.h2 = m.h2;
-                t.negInvH2 = -1.0f / m.h2;
-                float acc = 0.f;
-                int cnt = 0;
-                for (int r = 0; r < 9; r++) {
-                    const int h0 = halo_row(hc, r);
-                    for (int c3 = 0; c3 < 3; c3++) {
-                        const int h = h0 + c3;
-                        for (int pass = 0; pass < 2; pass++) {
-                            const float4 *__restrict__ src = pass ? bposm : posm;
-                            const int s0 = uniform_i(pass ? sh.bs[h] : sh.fs[h]);
-                            const int e0 = s0 + uniform_i(pass ? sh.bc[h] : sh.fc[h]);
-                            for (int k0 = s0; k0 < e0; k0 += S) {
-                                const int k = k0 + slice;
-                                float4 cd = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f);
-                                if (k < e0) cd = src[k];
-                                density_pair<COUNT>(t, cd, acc, cnt);
-                            }
-                        }
-                    }
-                }
-                wave_lds_fence();
-                red[lane] = acc;
-                if (COUNT) redc[lane] = cnt;
-                wave_lds_fence();
-                if (active && slice == 0) {
-                    float sum = 0.f;
-                    int c2 = 0;
-                    for (int q = 0; q < S; q++) {
-                        sum += red[lane + q];
-                        if (COUNT) c2 += redc[lane + q];
-                    }
-                    const float scale = COUNT ? m.poly6 : m.poly6 * (m.h2 * m.h2 * m.h2);
-                    const float density = scale * sum;
-                    const float pressure = fmaxf(m.gasConstant * (density - m.restDensity), 0.f);
-                    rho[ti] = density;
-                    prs[ti] = pressure;
-                    velq[ti].w = pressure / (density * density);
-                    if (COUNT) counts[ti] = c2;
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// force: pressure (spiky) + viscosity + gravity
-template <bool COUNT>
-__global__ __launch_bounds__(NB_THREADS) void k_force(
-    const float4 *__restrict__ posm, const float4 *__restrict__ velq,
-    const uint32_t *__restrict__ mat, const float *__restrict__ rho,
-    const float *__restrict__ prs, const int2 *__restrict__ table,
-    const int2 *__restrict__ ttable, const float4 *__restrict__ bposm,
-    const int2 *__restrict__ btable, GridDesc g, const Mat *__restrict__ mats, float gx, float gy,
-    float gz, float4 *__restrict__ force, int *__restrict__ counts, int cap,
-    const float4 *__restrict__ zeros)
-{
-    __shared__ TileShared sh;
-    __shared__ float4 recP[NB_FCAP + 1]; // x, y, z, m_j   (+ FAR record)
-    __shared__ float4 recV[NB_FCAP + 1]; // vx, vy, vz, q_j = p_j/rho_j^2 (boundary: 0,0,0,0)
-
-    const int tile = blockIdx.x;
-    const int2 trange = ttable[tile];
-    if (trange.y <= trange.x) return;
-    const int ntile = trange.y - trange.x;
-    const int total = tile_setup(sh, tile, g, table, btable);
-    const bool inLds = total <= cap && ntile <= NB_TCAP;
-    if (inLds) {
-        tile_stage<true>(sh, total, recP, recV, posm, velq, bposm, zeros);
-        // constants of the tile's own particles: -1/h, Cp, Cv, rho
-        for (int i = threadIdx.x; i < ntile; i += NB_THREADS) {
-            const Mat m = mats[mat[trange.x + i]];
-            const float d = rho[trange.x + i];
-            sh.tconst[i] = make_float4(-1.0f / m.h, d * m.spiky * (m.h * m.h),
-                                       m.viscosity / d * m.spiky * m.h, d);
-            if (COUNT) sh.tthr[i] = m.thrF;
-        }
-        if (threadIdx.x == 0) {
-            recP[NB_FCAP] = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f);
-            recV[NB_FCAP] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float *redx = sh.red[w][0], *redy = sh.red[w][1], *redz = sh.red[w][2];
-    int *redc = (int *)sh.red[w][3];
-    for (int ci = 0; ci < NB_CELLS_PER_WAVE; ci++) {
-        const int hc = halo_center(w * NB_CELLS_PER_WAVE + ci);
-        const int ncell = uniform_i(sh.fc[hc]);
-        const int cstart = uniform_i(sh.fs[hc]);
-        if (ncell == 0) continue;
-        const int clds = uniform_i(sh.pref[hc]);
+        const int per = (ncell + P - 1) / P;
+        const int t0 = part * per, t1 = min(ncell, t0 + per);
+        if (t0 >= t1) continue;
+        const int cstart = uniform_i(sh.fs[f]);
+        const int hcen = ((cz + 1) * hyN + (cy + 1)) * hxN + (cx + 1);
+        const int clds = uniform_i(sh.spref[hcen]);
+        const int tbase = uniform_i(sh.tpref[c]);
+        // lanes 0..8: LDS window of the nine (dy,dz) rows
         int rs = 0, re = 0;
-        if (inLds) row_windows(sh, hc, lane, rs, re);
-        for (int tb = 0; tb < ncell; tb += 64) {
-            const int T = min(64, ncell - tb);
+        if (lane < 9) {
+            const int h0 = hcen + ((lane / 3) - 1) * (hxN * hyN) + ((lane % 3) - 1) * hxN - 1;
+            rs = sh.spref[h0];
+            re = sh.spref[h0 + 3];
+        }
+        for (int tb = t0; tb < t1; tb += 64) {
+            const int T = min(64, t1 - tb);
             const int S = slices_for(T);
             int u, slice;
             split_lane(lane, S, u, slice);
             const bool active = u < T;
             const int tloc = tb + (active ? u : 0);
-            const int ti = cstart + tloc;
-            ForceTarget t;
-            ForceAcc a;
-            float Cp, Cv, trho;
-            if (inLds) {
-                const int selfK = clds + tloc; // LDS slot of the target itself
-                const float4 tp = recP[selfK], tv = recV[selfK];
-                const float4 tc = sh.tconst[cstart - trange.x + tloc];
-                t.x = tp.x; t.y = tp.y; t.z = tp.z;
-                t.vx = tv.x; t.vy = tv.y; t.vz = tv.z;
-                t.Pi = tv.w; // q_i = p_i / rho_i^2, written by the density kernel
-                t.negInvH = tc.x;
-                t.h = 0.f;
-                t.thrF = COUNT ? sh.tthr[cstart - trange.x + tloc] : 0.f;
-                Cp = tc.y; Cv = tc.z; trho = tc.w;
-#pragma unroll
-                for (int r = 0; r < 9; r++) {
-                    const int s0 = bcast_i(rs, r), e0 = bcast_i(re, r);
-                    float4 cp[NB_NQ], cv[NB_NQ];
-#pragma unroll
-                    for (int q = 0; q < NB_NQ; q++) {
-                        const int k = s0 + q * S + slice;
-                        const int kk = k < e0 ? k : NB_FCAP;
-                        cp[q] = recP[kk];
-                        cv[q] = recV[kk];
-                    }
-#pragma unroll
-                    for (int q = 0; q < NB_NQ; q++)
-                        force_pair<COUNT>(t, cp[q], cv[q], s0 + q * S + slice != selfK, a);
-                    for (int k0 = s0 + NB_NQ * S; k0 < e0; k0 += S) { // long windows
-                        const int k = k0 + slice;
-                        const int kk = k < e0 ? k : NB_FCAP;
-                        force_pair<COUNT>(t, recP[kk], recV[kk], k != selfK, a);
-                    }
-                }
+            const int selfK = clds + tloc; // LDS slot of the target itself
+            Pass<FORCE, COUNT> ps;
+            ps.tc = sh.tconst[tbase + tloc];
+            {
+                const float4 tp = recP[selfK];
+                ps.t.x = tp.x; ps.t.y = tp.y; ps.t.z = tp.z;
+            }
+            if constexpr (FORCE) {
+                const float4 tv = recV[selfK];
+                ps.t.vx = tv.x; ps.t.vy = tv.y; ps.t.vz = tv.z;
+                ps.t.Pi = tv.w; // q_i = p_i / rho_i^2, written by the density kernel
+                ps.t.negInvH = ps.tc.x;
+                ps.t.thrF = COUNT ? sh.tthr[tbase + tloc] : 0.f;
             } else {
-                // global-memory walk (halo does not fit the LDS tile)
-                const float4 tp = posm[ti], tv = velq[ti];
-                const Mat m = mats[mat[ti]];
-                trho = rho[ti];
-                t.x = tp.x; t.y = tp.y; t.z = tp.z;
-                t.vx = tv.x; t.vy = tv.y; t.vz = tv.z;
-                t.Pi = prs[ti] / (trho * trho);
-                t.h = m.h;
-                t.negInvH = -1.0f / m.h;
-                t.thrF = m.thrF;
-                Cp = trho * m.spiky * (m.h * m.h);       // rho_i * 45/(pi h^6) * h^2
-                Cv = m.viscosity / trho * m.spiky * m.h; // mu_i/rho_i * 45/(pi h^6) * h
-                for (int r = 0; r < 9; r++) {
-                    const int h0 = halo_row(hc, r);
-                    for (int c3 = 0; c3 < 3; c3++) {
-                        const int h = h0 + c3;
-                        { // fluid neighbours (index != j, :152)
-                            const int s0 = uniform_i(sh.fs[h]), e0 = s0 + uniform_i(sh.fc[h]);
-                            for (int k0 = s0; k0 < e0; k0 += S) {
-                                const int k = k0 + slice;
-                                float4 cp = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f);
-                                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-                                if (k < e0) {
-                                    cp = posm[k];
-                                    cv = velq[k];
-                                }
-                                force_pair<COUNT>(t, cp, cv, k != ti, a);
-                            }
-                        }
-                        { // boundary neighbours: rho_j = rho0_j, p_j = 0, v_j = 0 (:184-189)
-                            const int s0 = uniform_i(sh.bs[h]), e0 = s0 + uniform_i(sh.bc[h]);
-                            for (int k0 = s0; k0 < e0; k0 += S) {
-                                const int k = k0 + slice;
-                                float4 cp = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f);
-                                if (k < e0) cp = bposm[k];
-                                force_pair<COUNT>(t, cp, make_float4(0.f, 0.f, 0.f, 0.f), true, a);
-                            }
-                        }
+                ps.t.negInvH2 = ps.tc.x;
+                ps.t.h2 = COUNT ? sh.tthr[tbase + tloc] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 9; r++) {
+                const int s0 = bcast_i(rs, r), e0 = bcast_i(re, r);
+                for (int k0 = s0; k0 < e0; k0 += 4 * S) {
+                    float4 cp[4], cv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int k = k0 + q * S + slice;
+                        const int kk = k < e0 ? k : cap;
+                        cp[q] = recP[kk];
+                        if (FORCE) cv[q] = recV[kk]; else keep_b128(cp[q]);
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        ps.pair(cp[q], cv[q], k0 + q * S + slice != selfK);
                 }
             }
+            ps.finish(sh, A, w, lane, S, active && slice == 0, cstart + tloc);
+        }
+    }
+    __syncthreads(); // the LDS tile is reused by the next block
+    return true;
+}
 
-            // scale, fold the S slices of every target, add gravity
-            wave_lds_fence();
-            redx[lane] = Cp * a.px + Cv * a.vx;
-            redy[lane] = Cp * a.py + Cv * a.vy;
-            redz[lane] = Cp * a.pz + Cv * a.vz;
-            if (COUNT) redc[lane] = a.cnt;
-            wave_lds_fence();
-            if (active && slice == 0) {
-                float fx = 0.f, fy = 0.f, fz = 0.f;
-                int c2 = 0;
-                for (int q = 0; q < S; q++) {
-                    fx += redx[lane + q];
-                    fy += redy[lane + q];
-                    fz += redz[lane + q];
-                    if (COUNT) c2 += redc[lane + q];
+// one cell straight from global memory (its 27-cell neighbourhood overflows the LDS tile)
+template <bool FORCE, bool COUNT>
+__device__ void process_cell_global(TileShared &sh, const NbArgs &A, int lx, int ly, int lz)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int f = tile_halo_index(lx + 1, ly + 1, lz + 1);
+    const int ncell = uniform_i(sh.fc[f]);
+    const int cstart = uniform_i(sh.fs[f]);
+    const int per = (ncell + NB_WAVES - 1) / NB_WAVES; // the four waves share the targets
+    const int t0 = w * per, t1 = min(ncell, t0 + per);
+    for (int tb = t0; tb < t1; tb += 64) {
+        const int T = min(64, t1 - tb);
+        const int S = slices_for(T);
+        int u, slice;
+        split_lane(lane, S, u, slice);
+        const bool active = u < T;
+        const int ti = cstart + tb + (active ? u : 0);
+        Pass<FORCE, COUNT> ps;
+        float thr;
+        target_constants<FORCE, COUNT>(A, ti, ps.tc, thr);
+        const float4 tp = A.posm[ti];
+        ps.t.x = tp.x; ps.t.y = tp.y; ps.t.z = tp.z;
+        if constexpr (FORCE) {
+            const float4 tv = A.velq[ti];
+            ps.t.vx = tv.x; ps.t.vy = tv.y; ps.t.vz = tv.z;
+            ps.t.Pi = tv.w;
+            ps.t.negInvH = ps.tc.x;
+            ps.t.thrF = thr;
+        } else {
+            ps.t.negInvH2 = ps.tc.x;
+            ps.t.h2 = thr;
+        }
+        for (int c27 = 0; c27 < 27; c27++) {
+            const int h = f + ((c27 / 9) - 1) * (NB_HX * NB_HY) + (((c27 / 3) % 3) - 1) * NB_HX +
+                          (c27 % 3) - 1;
+            { // fluid neighbours (index != j, :152)
+                const int s0 = uniform_i(sh.fs[h]), e0 = s0 + uniform_i(sh.fc[h]);
+                for (int k0 = s0; k0 < e0; k0 += S) {
+                    const int k = k0 + slice;
+                    float4 cp = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f);
+                    float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < e0) {
+                        cp = A.posm[k];
+                        if (FORCE) cv = A.velq[k];
+                    }
+                    ps.pair(cp, cv, k != ti);
                 }
-                // forces = forcePressure + forceViscosity + gravity * rho_i  (:140,:202)
-                force[ti] = make_float4(fx + gx * trho, fy + gy * trho, fz + gz * trho, 0.f);
-                if (COUNT) counts[ti] = c2;
             }
+            { // boundary neighbours: rho_j = rho0_j, p_j = 0, v_j = 0 (:184-189)
+                const int s0 = uniform_i(sh.bs[h]), e0 = s0 + uniform_i(sh.bc[h]);
+                for (int k0 = s0; k0 < e0; k0 += S) {
+                    const int k = k0 + slice;
+                    float4 cp = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f);
+                    if (k < e0) cp = A.bposm[k];
+                    ps.pair(cp, make_float4(0.f, 0.f, 0.f, 0.f), true);
+                }
+            }
+        }
+        ps.finish(sh, A, w, lane, S, active && slice == 0, ti);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <bool FORCE, bool COUNT>
+__global__ __launch_bounds__(NB_THREADS) void k_neighbors(NbArgs A)
+{
+    __shared__ TileShared sh;
+    __shared__ float4 recP[(FORCE ? NB_FCAP : NB_DCAP) + 1]; // x, y, z, m_j (+ the FAR record)
+    __shared__ float4 recV[FORCE ? NB_FCAP + 1 : 1];         // vx, vy, vz, q_j = p_j/rho_j^2
+
+    const int tile = blockIdx.x;
+    const int2 trange = A.ttable[tile];
+    if (trange.y <= trange.x) return; // no fluid particle in this tile
+    tile_lookup(sh, tile, A);
+
+    if (process_block<FORCE, COUNT>(sh, recP, recV, A, 0, 0, 0, SPH_TX, SPH_TY, SPH_TZ)) return;
+    for (int sb = 0; sb < 8; sb++) { // 2x2x1 sub-blocks
+        const int bx = (sb & 1) * 2, by = ((sb >> 1) & 1) * 2, bz = sb >> 2;
+        if (process_block<FORCE, COUNT>(sh, recP, recV, A, bx, by, bz, 2, 2, 1)) continue;
+        for (int c = 0; c < 4; c++) { // single cells
+            const int lx = bx + (c & 1), ly = by + (c >> 1);
+            if (process_block<FORCE, COUNT>(sh, recP, recV, A, lx, ly, bz, 1, 1, 1)) continue;
+            process_cell_global<FORCE, COUNT>(sh, A, lx, ly, bz);
+            __syncthreads();
         }
     }
 }

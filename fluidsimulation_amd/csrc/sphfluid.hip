@@ -864,6 +864,33 @@ int sph_reorder(SphCtx *c)
     return SPH_OK;
 }
 
+static NbArgs neighbor_args(SphCtx *c, const SphParams *p, int cap)
+{
+    const int cur = c->cur;
+    NbArgs A{};
+    A.posm = c->posm[cur].p;
+    A.velq = c->velq[cur].p;
+    A.mat = c->mat[cur].p;
+    A.rhoIn = c->rho.p;
+    A.prsIn = c->prs.p;
+    A.table = c->table.p;
+    A.ttable = c->ttable.p;
+    A.btable = c->nb > 0 ? c->btable.p : nullptr;
+    A.bposm = c->nb > 0 ? c->bposm.p : nullptr;
+    A.mats = c->dmats.p;
+    A.zeros = c->zeros.p;
+    A.rho = c->rho.p;
+    A.prs = c->prs.p;
+    A.force = c->force.p;
+    A.counts = nullptr;
+    A.g = c->grid;
+    A.gx = p->gravity[0];
+    A.gy = p->gravity[1];
+    A.gz = p->gravity[2];
+    A.cap = c->fallbackCap >= 0 ? std::min(c->fallbackCap, cap) : cap;
+    return A;
+}
+
 int sph_compute_density_and_pressure(SphCtx *c, const SphParams *p)
 {
     int rc = check_params(c, p);
@@ -872,18 +899,13 @@ int sph_compute_density_and_pressure(SphCtx *c, const SphParams *p)
     rc = ensure_debug(c);
     if (rc) return rc;
     StageTimer t(c, SPH_T_DENSITY);
-    const int cur = c->cur;
-    const float4 *bp = c->nb > 0 ? c->bposm.p : nullptr;
-    const int2 *bt = c->nb > 0 ? c->btable.p : nullptr;
-    const int cap = c->fallbackCap >= 0 ? std::min(c->fallbackCap, NB_DCAP) : NB_DCAP;
-    if (c->debug & SPH_DEBUG_COUNTS)
-        k_density<true><<<c->grid.tiles, NB_THREADS, 0, c->stream>>>(
-            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->table.p, c->ttable.p, bp, bt,
-            c->grid, c->dmats.p, c->rho.p, c->prs.p, c->dcount.p, cap);
-    else
-        k_density<false><<<c->grid.tiles, NB_THREADS, 0, c->stream>>>(
-            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->table.p, c->ttable.p, bp, bt,
-            c->grid, c->dmats.p, c->rho.p, c->prs.p, nullptr, cap);
+    NbArgs A = neighbor_args(c, p, NB_DCAP);
+    if (c->debug & SPH_DEBUG_COUNTS) {
+        A.counts = c->dcount.p;
+        k_neighbors<false, true><<<c->grid.tiles, NB_THREADS, 0, c->stream>>>(A);
+    } else {
+        k_neighbors<false, false><<<c->grid.tiles, NB_THREADS, 0, c->stream>>>(A);
+    }
     HIPCHK(c, hipGetLastError());
     c->haveDensity = true;
     return SPH_OK;
@@ -895,20 +917,13 @@ int sph_compute_force(SphCtx *c, const SphParams *p)
     if (rc) return rc;
     if (!c->haveDensity) return fail(c, SPH_E_INVALID, "force before density");
     StageTimer t(c, SPH_T_FORCE);
-    const int cur = c->cur;
-    const float4 *bp = c->nb > 0 ? c->bposm.p : nullptr;
-    const int2 *bt = c->nb > 0 ? c->btable.p : nullptr;
-    const int cap = c->fallbackCap >= 0 ? std::min(c->fallbackCap, NB_FCAP) : NB_FCAP;
-    if (c->debug & SPH_DEBUG_COUNTS)
-        k_force<true><<<c->grid.tiles, NB_THREADS, 0, c->stream>>>(
-            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->rho.p, c->prs.p, c->table.p,
-            c->ttable.p, bp, bt, c->grid, c->dmats.p, p->gravity[0], p->gravity[1], p->gravity[2],
-            c->force.p, c->fcount.p, cap, c->zeros.p);
-    else
-        k_force<false><<<c->grid.tiles, NB_THREADS, 0, c->stream>>>(
-            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->rho.p, c->prs.p, c->table.p,
-            c->ttable.p, bp, bt, c->grid, c->dmats.p, p->gravity[0], p->gravity[1], p->gravity[2],
-            c->force.p, nullptr, cap, c->zeros.p);
+    NbArgs A = neighbor_args(c, p, NB_FCAP);
+    if (c->debug & SPH_DEBUG_COUNTS) {
+        A.counts = c->fcount.p;
+        k_neighbors<true, true><<<c->grid.tiles, NB_THREADS, 0, c->stream>>>(A);
+    } else {
+        k_neighbors<true, false><<<c->grid.tiles, NB_THREADS, 0, c->stream>>>(A);
+    }
     HIPCHK(c, hipGetLastError());
     c->haveForce = true;
     return SPH_OK;

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Cell / tile occupancy of a config after n steps (why the neighbour kernels slow down or take
+the global-memory path): python tools/occupancy_stats.py C3 150"""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fluidsimulation_amd import native, scene
+
+cfg, nsteps = sys.argv[1], int(sys.argv[2])
+sc = scene.make_config(cfg)
+p = native.make_params(sc.grid_size, body_bounds=(sc.tank_min, sc.tank_max))
+ctx = native.Context(timings=True)
+ctx.set_boundary(sc.bpos, sc.bparams)
+ctx.set_colliders(sc.boxes)
+ctx.upload(sc.pos, sc.vel, sc.inv_mass, sc.params, sc.grid_size)
+for chunk in range(0, nsteps, 50):
+    ctx.step_resident(p, min(50, nsteps - chunk))
+    pos, vel = ctx.download()
+    origin, dims, bits, ncells = ctx.get_grid()
+    c = np.floor(pos / sc.grid_size).astype(np.int64) - np.array(origin)
+    c %= np.array(dims)
+    lin = (c[:, 2] * dims[1] + c[:, 1]) * dims[0] + c[:, 0]
+    occ = np.bincount(lin, minlength=ncells).reshape(dims[2], dims[1], dims[0])
+    bc = np.floor(sc.bpos / sc.grid_size).astype(np.int64) - np.array(origin)
+    bc %= np.array(dims)
+    blin = (bc[:, 2] * dims[1] + bc[:, 1]) * dims[0] + bc[:, 0]
+    bocc = np.bincount(blin, minlength=ncells).reshape(dims[2], dims[1], dims[0])
+    nz = occ[occ > 0]
+    print(f"after {chunk + 50} steps: cells occupied {nz.size}, mean {nz.mean():.2f} max {nz.max()} "
+          f"p50 {np.percentile(nz, 50):.0f} p90 {np.percentile(nz, 90):.0f} p99 {np.percentile(nz, 99):.0f}; "
+          f"|v|max {np.abs(vel).max():.2f} finite {np.isfinite(pos).all()}")
+    tot = occ + bocc
+    # halo totals per tile (4x4x2 tiles, 6x6x4 halo) via padded cumulative sums
+    pad = np.pad(tot, 1, mode="wrap")
+    cs = pad.cumsum(0).cumsum(1).cumsum(2)
+    cs = np.pad(cs, ((1, 0), (1, 0), (1, 0)))
+    def box(z0, z1, y0, y1, x0, x1):
+        return (cs[z1, y1, x1] - cs[z0, y1, x1] - cs[z1, y0, x1] - cs[z1, y1, x0]
+                + cs[z0, y0, x1] + cs[z0, y1, x0] + cs[z1, y0, x0] - cs[z0, y0, x0])
+    tz, ty, tx = dims[2] // 2, dims[1] // 4, dims[0] // 4
+    Z, Y, X = np.meshgrid(np.arange(tz) * 2, np.arange(ty) * 4, np.arange(tx) * 4, indexing="ij")
+    halo = box(Z, Z + 4, Y, Y + 6, X, X + 6)
+    own = occ.reshape(tz, 2, ty, 4, tx, 4).sum(axis=(1, 3, 5))
+    live = own > 0
+    h = halo[live]
+    print(f"   tiles with fluid {live.sum()}, halo records mean {h.mean():.0f} p90 {np.percentile(h, 90):.0f} "
+          f"p99 {np.percentile(h, 99):.0f} max {h.max()}; > 2048: {np.mean(h > 2048):.3f}, > 1792: "
+          f"{np.mean(h > 1792):.3f}; own > 512: {np.mean(own[live] > 512):.4f}")
+    t = ctx.timings(); ctx.reset_timings()
+    print("   stage ms/step:", {k: round(v / max(t['steps'], 1), 3) for k, v in t['ms'].items()})
