@@ -53,8 +53,9 @@ struct TileShared {
     int hmap[NB_HCELLS];      // block halo cell -> tile halo cell
     int spref[NB_HCELLS + 1]; // LDS offset of the block halo cell's records (fluid, then boundary)
     int tpref[SPH_TCELLS + 1]; // ordinal of the first target of every cell of the block
+    int2 cellf[SPH_TCELLS]; // per block cell: halo index in the tile, halo index in the block
+    int4 cdesc[SPH_TCELLS];    // per cell of the block: targets, global start, LDS start, ordinal
     int scan[2 * NB_WAVES];
-    float red[NB_WAVES][4][64];
     float4 tconst[NB_TCAP];   // per-target constants of the block's own particles
     float tthr[NB_TCAP];      // COUNT variants: the exact predicate threshold (h2 / thrF)
 };
@@ -76,6 +77,7 @@ struct NbArgs {
     GridDesc g;
     float gx, gy, gz;
     int cap;
+    int ablate; // profiling only: 1 = skip the compute phase, 2 = skip the row walk
 };
 
 __device__ __forceinline__ int wrapi(int c, int g) { return c < 0 ? c + g : (c >= g ? c - g : c); }
@@ -83,7 +85,7 @@ __device__ __forceinline__ int wrapi(int c, int g) { return c < 0 ? c + g : (c >
 // lane -> (target slot u, slice) for T targets and S = 64 / T slices
 __device__ __forceinline__ void split_lane(int lane, int S, int &u, int &slice)
 {
-    u = (int)(((float)lane + 0.5f) * (1.0f / (float)S)); // exact for lane < 64
+    u = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)S)); // exact for lane < 64
     slice = lane - u * S;
 }
 // S = floor(64 / T) without an integer division
@@ -99,6 +101,47 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// inclusive scan inside each row of 16 lanes (DPP row_shr, zeros shifted in)
+__device__ __forceinline__ int row16_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true); // row_shr:8
+    return v;
+}
+
+// Sum over the S consecutive lanes of a slice group, valid in the group's first lane (slice 0).
+// Groups of 2/4/8/16 lanes never straddle a DPP row of 16, larger or odd groups go through
+// ds_bpermute.  The order of the additions depends only on S.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int N> __device__ __forceinline__ void fold_slices(float (&v)[N], int &c, int S, int slice)
+{
+    if ((S & (S - 1)) == 0 && S <= 16) { // row_shl:d, zeros shifted in
+        if (S >= 2) { for (int k = 0; k < N; k++) v[k] += dpp_f<0x101>(v[k]); c += dpp_i<0x101>(c); }
+        if (S >= 4) { for (int k = 0; k < N; k++) v[k] += dpp_f<0x102>(v[k]); c += dpp_i<0x102>(c); }
+        if (S >= 8) { for (int k = 0; k < N; k++) v[k] += dpp_f<0x104>(v[k]); c += dpp_i<0x104>(c); }
+        if (S >= 16) { for (int k = 0; k < N; k++) v[k] += dpp_f<0x108>(v[k]); c += dpp_i<0x108>(c); }
+    } else {
+        for (int d = 1; d < S; d <<= 1) {
+            const bool in = slice + d < S;
+            float x[N];
+            for (int k = 0; k < N; k++) x[k] = __shfl_down(v[k], d, 64);
+            const int xc = __shfl_down(c, d, 64);
+            for (int k = 0; k < N; k++) v[k] += in ? x[k] : 0.f;
+            c += in ? xc : 0;
+        }
+    }
 }
 
 // last index i in [0, n) with a[i] <= q (a non-decreasing, a[0] <= q)
@@ -250,22 +293,13 @@ template <bool COUNT> struct Pass<false, COUNT> {
         density_pair<COUNT>(t, cp, acc, cnt);
     }
     // folds the slices and writes rho, p, q for target ti
-    __device__ __forceinline__ void finish(TileShared &sh, const NbArgs &A, int w, int lane, int S,
-                                           bool writer, int ti)
+    __device__ __forceinline__ void finish(const NbArgs &A, int S, int slice, bool writer, int ti)
     {
-        float *red = sh.red[w][0];
-        int *redc = (int *)sh.red[w][1];
-        wave_lds_fence();
-        red[lane] = acc;
-        if (COUNT) redc[lane] = cnt;
-        wave_lds_fence();
+        float v[1] = {acc};
+        int c2 = cnt;
+        fold_slices<1>(v, c2, S, slice);
         if (writer) {
-            float sum = 0.f;
-            int c2 = 0;
-            for (int q = 0; q < S; q++) {
-                sum += red[lane + q];
-                if (COUNT) c2 += redc[lane + q];
-            }
+            const float sum = v[0];
             // rho_i = m_i*315/(64*pi*h^9) * sum (h2-d2)^3 ; p_i = max(k (rho_i - rho0), 0)
             const float density = tc.y * sum;
             const float pressure = fmaxf(tc.z * (density - tc.w), 0.f);
@@ -285,26 +319,13 @@ template <bool COUNT> struct Pass<true, COUNT> {
     {
         force_pair<COUNT>(t, cp, cv, notSelf, a);
     }
-    __device__ __forceinline__ void finish(TileShared &sh, const NbArgs &A, int w, int lane, int S,
-                                           bool writer, int ti)
+    __device__ __forceinline__ void finish(const NbArgs &A, int S, int slice, bool writer, int ti)
     {
-        float *redx = sh.red[w][0], *redy = sh.red[w][1], *redz = sh.red[w][2];
-        int *redc = (int *)sh.red[w][3];
-        wave_lds_fence();
-        redx[lane] = tc.y * a.px + tc.z * a.vx;
-        redy[lane] = tc.y * a.py + tc.z * a.vy;
-        redz[lane] = tc.y * a.pz + tc.z * a.vz;
-        if (COUNT) redc[lane] = a.cnt;
-        wave_lds_fence();
+        float v[3] = {tc.y * a.px + tc.z * a.vx, tc.y * a.py + tc.z * a.vy, tc.y * a.pz + tc.z * a.vz};
+        int c2 = a.cnt;
+        fold_slices<3>(v, c2, S, slice);
         if (writer) {
-            float fx = 0.f, fy = 0.f, fz = 0.f;
-            int c2 = 0;
-            for (int q = 0; q < S; q++) {
-                fx += redx[lane + q];
-                fy += redy[lane + q];
-                fz += redz[lane + q];
-                if (COUNT) c2 += redc[lane + q];
-            }
+            const float fx = v[0], fy = v[1], fz = v[2];
             // forces = forcePressure + forceViscosity + gravity * rho_i  (:140,:202)
             const float trho = tc.w;
             A.force[ti] =
@@ -352,7 +373,9 @@ __device__ bool process_block(TileShared &sh, float4 *recP, float4 *recV, const 
     }
     if (tid < ncells) {
         const int cx = tid % sx, cy = (tid / sx) % sy, cz = tid / (sx * sy);
-        tcnt = sh.fc[tile_halo_index(bx0 + cx + 1, by0 + cy + 1, bz0 + cz + 1)];
+        const int f = tile_halo_index(bx0 + cx + 1, by0 + cy + 1, bz0 + cz + 1);
+        tcnt = sh.fc[f];
+        sh.cellf[tid] = make_int2(f, ((cz + 1) * hyN + (cy + 1)) * hxN + (cx + 1));
     }
     int e1, e2, total, ttotal;
     block_scan2(sh, cnt, tcnt, e1, e2, total, ttotal);
@@ -386,13 +409,16 @@ __device__ bool process_block(TileShared &sh, float4 *recP, float4 *recV, const 
     }
     for (int i = tid; i < ttotal; i += NB_THREADS) {
         const int c = bisect_le(sh.tpref, ncells, i);
-        const int cx = c % sx, cy = (c / sx) % sy, cz = c / (sx * sy);
-        const int f = tile_halo_index(bx0 + cx + 1, by0 + cy + 1, bz0 + cz + 1);
+        const int f = sh.cellf[c].x;
         float4 tc;
         float thr;
         target_constants<FORCE, COUNT>(A, sh.fs[f] + (i - sh.tpref[c]), tc, thr);
         sh.tconst[i] = tc;
         if (COUNT) sh.tthr[i] = thr;
+    }
+    if (tid < ncells) {
+        const int2 cf = sh.cellf[tid];
+        sh.cdesc[tid] = make_int4(sh.fc[cf.x] | (cf.y << 16), sh.fs[cf.x], sh.spref[cf.y], sh.tpref[tid]);
     }
     if (tid == 0) {
         recP[cap] = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f); // what padding lanes read
@@ -401,43 +427,52 @@ __device__ bool process_block(TileShared &sh, float4 *recP, float4 *recV, const 
     __syncthreads();
 
     // 3. units = (cell, part); a part is a contiguous share of the cell's targets
-    const int P = ncells >= NB_WAVES ? 1 : NB_WAVES / ncells;
-    for (int unit = w; unit < ncells * P; unit += NB_WAVES) {
-        const int c = unit / P, part = unit - c * P;
-        const int cx = c % sx, cy = (c / sx) % sy, cz = c / (sx * sy);
-        const int f = tile_halo_index(bx0 + cx + 1, by0 + cy + 1, bz0 + cz + 1);
-        const int ncell = uniform_i(sh.fc[f]);
+    const int pshift = ncells >= NB_WAVES ? 0 : ncells == 1 ? 2 : 1; // parts per cell = 1 << pshift
+    const int P = 1 << pshift;
+    // lanes 0..8: halo-cell offset of the first cell of row (dy,dz) relative to the centre cell
+    const int rowOff = ((lane / 3) - 1) * (hxN * hyN) + ((lane % 3) - 1) * hxN - 1;
+    const char *baseP = (const char *)recP, *baseV = (const char *)recV;
+    const int far16 = cap * 16;
+    for (int unit = w; unit < ncells * P && !(A.ablate & 1); unit += NB_WAVES) {
+        const int c = unit >> pshift, part = unit - (c << pshift);
+        const int4 cd = sh.cdesc[c];
+        const int ncell = uniform_i(cd.x) & 0xffff, hcen = uniform_i(cd.x) >> 16;
         if (ncell == 0) continue;
-        const int per = (ncell + P - 1) / P;
+        const int per = (ncell + P - 1) >> pshift;
         const int t0 = part * per, t1 = min(ncell, t0 + per);
         if (t0 >= t1) continue;
-        const int cstart = uniform_i(sh.fs[f]);
-        const int hcen = ((cz + 1) * hyN + (cy + 1)) * hxN + (cx + 1);
-        const int clds = uniform_i(sh.spref[hcen]);
-        const int tbase = uniform_i(sh.tpref[c]);
-        // lanes 0..8: LDS window of the nine (dy,dz) rows
-        int rs = 0, re = 0;
+        const int cstart = uniform_i(cd.y), clds = uniform_i(cd.z), tbase = uniform_i(cd.w);
+        // lanes 0..8: LDS window (byte offsets) of the nine (dy,dz) rows.  The nine windows are
+        // walked as ONE candidate stream: entry p of the piece table gives the stream offset at
+        // which window p ends and the delta from stream offset to LDS offset inside it.
+        int rs = 0, len = 0;
         if (lane < 9) {
-            const int h0 = hcen + ((lane / 3) - 1) * (hxN * hyN) + ((lane % 3) - 1) * hxN - 1;
-            rs = sh.spref[h0];
-            re = sh.spref[h0 + 3];
+            const int h0 = hcen + rowOff;
+            rs = sh.spref[h0] * 16;
+            len = sh.spref[h0 + 3] * 16 - rs;
         }
+        const int incl = row16_incl_scan(len);
+        const int Vtot = (A.ablate & 2) ? 0 : bcast_i(incl, 8); // bytes of all candidate records of this cell
+        const int pend = lane < 9 ? incl : 0x7fffffff;           // lane p: stream offset where window p ends
+        const int pdelta = rs - (incl - len);                    // lane p: LDS offset - stream offset in window p
         for (int tb = t0; tb < t1; tb += 64) {
             const int T = min(64, t1 - tb);
             const int S = slices_for(T);
+            const int S16 = S * 16;
             int u, slice;
             split_lane(lane, S, u, slice);
+            const int slice16 = slice * 16;
             const bool active = u < T;
             const int tloc = tb + (active ? u : 0);
-            const int selfK = clds + tloc; // LDS slot of the target itself
+            const int self16 = (clds + tloc) * 16; // LDS byte offset of the target itself
             Pass<FORCE, COUNT> ps;
             ps.tc = sh.tconst[tbase + tloc];
             {
-                const float4 tp = recP[selfK];
+                const float4 tp = *(const float4 *)(baseP + self16);
                 ps.t.x = tp.x; ps.t.y = tp.y; ps.t.z = tp.z;
             }
             if constexpr (FORCE) {
-                const float4 tv = recV[selfK];
+                const float4 tv = *(const float4 *)(baseV + self16);
                 ps.t.vx = tv.x; ps.t.vy = tv.y; ps.t.vz = tv.z;
                 ps.t.Pi = tv.w; // q_i = p_i / rho_i^2, written by the density kernel
                 ps.t.negInvH = ps.tc.x;
@@ -446,24 +481,62 @@ __device__ bool process_block(TileShared &sh, float4 *recP, float4 *recV, const 
                 ps.t.negInvH2 = ps.tc.x;
                 ps.t.h2 = COUNT ? sh.tthr[tbase + tloc] : 0.f;
             }
+            // Cursor into the stream.  Slot k covers stream bytes [k*S16, (k+1)*S16); lane `slice`
+            // reads offset k*S16 + slice16.  The window the slot starts in is wave-uniform (SGPRs,
+            // fetched with readlane); lanes behind a window end inside the slot switch delta.
+            int cur = 0;
+            int vendS = __builtin_amdgcn_readlane(pend, 0), deltaS = __builtin_amdgcn_readlane(pdelta, 0);
+            int base = 0; // stream offset of the current slot (uniform)
+            auto next_slot = [&]() -> int {
+                int a = slice16 + (base + deltaS);
+                while (vendS < base + S16) { // a window ends inside this slot (the sentinel never does)
+                    cur++;
+                    const int nd = __builtin_amdgcn_readlane(pdelta, cur);
+                    a += (slice16 >= vendS - base) ? (nd - deltaS) : 0;
+                    vendS = __builtin_amdgcn_readlane(pend, cur);
+                    deltaS = nd;
+                }
+                base += S16;
+                return a;
+            };
+            constexpr int G = FORCE ? 4 : 8; // slots in flight
+            int vb = 0;
+            // full groups: every lane reads a valid record
+            for (; vb + G * S16 <= Vtot; vb += G * S16) {
+                float4 cp[G], cv[G];
+                int off[G];
 #pragma unroll
-            for (int r = 0; r < 9; r++) {
-                const int s0 = bcast_i(rs, r), e0 = bcast_i(re, r);
-                for (int k0 = s0; k0 < e0; k0 += 4 * S) {
-                    float4 cp[4], cv[4];
+                for (int q = 0; q < G; q++) {
+                    off[q] = next_slot();
+                    cp[q] = *(const float4 *)(baseP + off[q]);
+                    if (FORCE) cv[q] = *(const float4 *)(baseV + off[q]);
+                }
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int k = k0 + q * S + slice;
-                        const int kk = k < e0 ? k : cap;
-                        cp[q] = recP[kk];
-                        if (FORCE) cv[q] = recV[kk]; else keep_b128(cp[q]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        ps.pair(cp[q], cv[q], k0 + q * S + slice != selfK);
+                for (int q = 0; q < G; q++) {
+                    if (!FORCE) keep_b128(cp[q]);
+                    ps.pair(cp[q], cv[q], off[q] != self16);
                 }
             }
-            ps.finish(sh, A, w, lane, S, active && slice == 0, cstart + tloc);
+            // last group: lanes past the stream read the FAR record, empty slots are skipped
+            if (vb < Vtot) {
+                float4 cp[G], cv[G];
+                int off[G];
+#pragma unroll
+                for (int q = 0; q < G; q++) {
+                    const int a = next_slot();
+                    off[q] = vb + q * S16 + slice16 < Vtot ? a : far16;
+                    cp[q] = *(const float4 *)(baseP + off[q]);
+                    if (FORCE) cv[q] = *(const float4 *)(baseV + off[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < G; q++) {
+                    if (vb + q * S16 < Vtot) { // wave-uniform
+                        if (!FORCE) keep_b128(cp[q]);
+                        ps.pair(cp[q], cv[q], off[q] != self16);
+                    }
+                }
+            }
+            ps.finish(A, S, slice, active && slice == 0, cstart + tloc);
         }
     }
     __syncthreads(); // the LDS tile is reused by the next block
@@ -528,7 +601,7 @@ __device__ void process_cell_global(TileShared &sh, const NbArgs &A, int lx, int
                 }
             }
         }
-        ps.finish(sh, A, w, lane, S, active && slice == 0, ti);
+        ps.finish(A, S, slice, active && slice == 0, ti);
     }
 }
 

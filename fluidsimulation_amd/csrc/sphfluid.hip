@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -888,6 +889,7 @@ static NbArgs neighbor_args(SphCtx *c, const SphParams *p, int cap)
     A.gy = p->gravity[1];
     A.gz = p->gravity[2];
     A.cap = c->fallbackCap >= 0 ? std::min(c->fallbackCap, cap) : cap;
+    if (const char *e = getenv("SPH_ABLATE")) A.ablate = atoi(e);
     return A;
 }
 
