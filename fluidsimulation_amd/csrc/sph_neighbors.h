@@ -39,10 +39,25 @@
 #define NB_HY (SPH_TY + 2)
 #define NB_HZ (SPH_TZ + 2)
 #define NB_HCELLS (NB_HX * NB_HY * NB_HZ) // 144
-#define NB_THREADS 256
-#define NB_WAVES 4
-#define NB_DCAP 2048 // LDS records per block, density kernel (32 KB)
-#define NB_FCAP 1792 // LDS records per block, force kernel (2 x 28 KB)
+#ifndef NB_DTHREADS
+#define NB_DTHREADS 256 // workgroup size of the density kernel
+#endif
+#ifndef NB_FTHREADS
+#define NB_FTHREADS 256 // workgroup size of the force kernel
+#endif
+#define NB_MAXWAVES 8
+#ifndef NB_DG
+#define NB_DG 4 // candidate records in flight per lane, density
+#endif
+#ifndef NB_FG
+#define NB_FG 4 // same, force
+#endif
+#ifndef NB_DCAP
+#define NB_DCAP 1536 // LDS records per block, density kernel (24 KB): four workgroups per CU
+#endif
+#ifndef NB_FCAP
+#define NB_FCAP 1216 // LDS records per block, force kernel (2 x 19 KB): three workgroups per CU
+#endif
 #define NB_TCAP 512  // targets per block whose constants are cached in LDS
 
 struct TileShared {
@@ -55,9 +70,8 @@ struct TileShared {
     int tpref[SPH_TCELLS + 1]; // ordinal of the first target of every cell of the block
     int2 cellf[SPH_TCELLS]; // per block cell: halo index in the tile, halo index in the block
     int4 cdesc[SPH_TCELLS];    // per cell of the block: targets, global start, LDS start, ordinal
-    int scan[2 * NB_WAVES];
+    int scan[2 * NB_MAXWAVES];
     float4 tconst[NB_TCAP];   // per-target constants of the block's own particles
-    float tthr[NB_TCAP];      // COUNT variants: the exact predicate threshold (h2 / thrF)
 };
 
 // kernel arguments shared by both passes
@@ -160,7 +174,7 @@ __device__ __forceinline__ int bisect_le(const int *a, int n, int q)
 __device__ __forceinline__ void block_scan2(TileShared &sh, int a, int b, int &ea, int &eb,
                                             int &ta, int &tb)
 {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int ia = a, ib = b;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -173,7 +187,8 @@ __device__ __forceinline__ void block_scan2(TileShared &sh, int a, int b, int &e
     int ba = 0, bb = 0;
     ta = 0; tb = 0;
 #pragma unroll
-    for (int i = 0; i < NB_WAVES; i++) {
+    for (int i = 0; i < NB_MAXWAVES; i++) {
+        if (i >= nw) break;
         const int xa = sh.scan[2 * i], xb = sh.scan[2 * i + 1];
         if (i < w) { ba += xa; bb += xb; }
         ta += xa; tb += xb;
@@ -355,10 +370,11 @@ __device__ __forceinline__ void target_constants(const NbArgs &A, int gi, float4
 // ------------------------------------------------------------------------------------------
 // one block (bx0.., sx x sy x sz cells, tile-local) through the LDS tile.  Returns false, having
 // done nothing, when the block's halo or its targets do not fit.
-template <bool FORCE, bool COUNT>
-__device__ bool process_block(TileShared &sh, float4 *recP, float4 *recV, const NbArgs &A,
-                              int bx0, int by0, int bz0, int sx, int sy, int sz)
+template <bool FORCE, bool COUNT, int sx, int sy, int sz>
+__device__ __forceinline__ bool process_block(TileShared &sh, float4 *recP, float4 *recV, float *tthr,
+                                              const NbArgs &A, int bx0, int by0, int bz0)
 {
+    constexpr int NB_THREADS = FORCE ? NB_FTHREADS : NB_DTHREADS, NB_WAVES = NB_THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int hxN = sx + 2, hyN = sy + 2, nh = hxN * hyN * (sz + 2), ncells = sx * sy * sz;
     const int cap = A.cap;
@@ -414,7 +430,7 @@ __device__ bool process_block(TileShared &sh, float4 *recP, float4 *recV, const 
         float thr;
         target_constants<FORCE, COUNT>(A, sh.fs[f] + (i - sh.tpref[c]), tc, thr);
         sh.tconst[i] = tc;
-        if (COUNT) sh.tthr[i] = thr;
+        if (COUNT) tthr[i] = thr;
     }
     if (tid < ncells) {
         const int2 cf = sh.cellf[tid];
@@ -427,30 +443,39 @@ __device__ bool process_block(TileShared &sh, float4 *recP, float4 *recV, const 
     __syncthreads();
 
     // 3. units = (cell, part); a part is a contiguous share of the cell's targets
-    const int pshift = ncells >= NB_WAVES ? 0 : ncells == 1 ? 2 : 1; // parts per cell = 1 << pshift
+    // parts per cell = 1 << pshift (blocks are 32, 4 or 1 cells)
+    const int pshift = ncells >= NB_WAVES ? 0 : __builtin_ctz(NB_WAVES) - (ncells == 1 ? 0 : 2);
     const int P = 1 << pshift;
     // lanes 0..8: halo-cell offset of the first cell of row (dy,dz) relative to the centre cell
     const int rowOff = ((lane / 3) - 1) * (hxN * hyN) + ((lane % 3) - 1) * hxN - 1;
     const char *baseP = (const char *)recP, *baseV = (const char *)recV;
     const int far16 = cap * 16;
-    for (int unit = w; unit < ncells * P && !(A.ablate & 1); unit += NB_WAVES) {
+    // the descriptor and the nine windows of a unit are fetched one unit ahead of their use
+    const int nunits = (A.ablate & 1) ? 0 : ncells << pshift;
+    int4 cdN = make_int4(0, 0, 0, 0);
+    int rsN = 0, lenN = 0;
+    auto prefetch = [&](int unit) {
+        if (unit < nunits) {
+            cdN = sh.cdesc[unit >> pshift];
+            if (lane < 9) {
+                const int h0 = (cdN.x >> 16) + rowOff;
+                rsN = sh.spref[h0] * 16;
+                lenN = sh.spref[h0 + 3] * 16 - rsN;
+            }
+        }
+    };
+    prefetch(w);
+    for (int unit = w; unit < nunits; unit += NB_WAVES) {
         const int c = unit >> pshift, part = unit - (c << pshift);
-        const int4 cd = sh.cdesc[c];
-        const int ncell = uniform_i(cd.x) & 0xffff, hcen = uniform_i(cd.x) >> 16;
+        const int4 cd = cdN;
+        const int rs = lane < 9 ? rsN : 0, len = lane < 9 ? lenN : 0;
+        prefetch(unit + NB_WAVES);
+        const int ncell = uniform_i(cd.x) & 0xffff;
         if (ncell == 0) continue;
         const int per = (ncell + P - 1) >> pshift;
         const int t0 = part * per, t1 = min(ncell, t0 + per);
         if (t0 >= t1) continue;
         const int cstart = uniform_i(cd.y), clds = uniform_i(cd.z), tbase = uniform_i(cd.w);
-        // lanes 0..8: LDS window (byte offsets) of the nine (dy,dz) rows.  The nine windows are
-        // walked as ONE candidate stream: entry p of the piece table gives the stream offset at
-        // which window p ends and the delta from stream offset to LDS offset inside it.
-        int rs = 0, len = 0;
-        if (lane < 9) {
-            const int h0 = hcen + rowOff;
-            rs = sh.spref[h0] * 16;
-            len = sh.spref[h0 + 3] * 16 - rs;
-        }
         const int incl = row16_incl_scan(len);
         const int Vtot = (A.ablate & 2) ? 0 : bcast_i(incl, 8); // bytes of all candidate records of this cell
         const int pend = lane < 9 ? incl : 0x7fffffff;           // lane p: stream offset where window p ends
@@ -476,10 +501,10 @@ __device__ bool process_block(TileShared &sh, float4 *recP, float4 *recV, const 
                 ps.t.vx = tv.x; ps.t.vy = tv.y; ps.t.vz = tv.z;
                 ps.t.Pi = tv.w; // q_i = p_i / rho_i^2, written by the density kernel
                 ps.t.negInvH = ps.tc.x;
-                ps.t.thrF = COUNT ? sh.tthr[tbase + tloc] : 0.f;
+                ps.t.thrF = COUNT ? tthr[tbase + tloc] : 0.f;
             } else {
                 ps.t.negInvH2 = ps.tc.x;
-                ps.t.h2 = COUNT ? sh.tthr[tbase + tloc] : 0.f;
+                ps.t.h2 = COUNT ? tthr[tbase + tloc] : 0.f;
             }
             // Cursor into the stream.  Slot k covers stream bytes [k*S16, (k+1)*S16); lane `slice`
             // reads offset k*S16 + slice16.  The window the slot starts in is wave-uniform (SGPRs,
@@ -499,7 +524,7 @@ __device__ bool process_block(TileShared &sh, float4 *recP, float4 *recV, const 
                 base += S16;
                 return a;
             };
-            constexpr int G = FORCE ? 4 : 8; // slots in flight
+            constexpr int G = FORCE ? NB_FG : NB_DG; // slots in flight
             int vb = 0;
             // full groups: every lane reads a valid record
             for (; vb + G * S16 <= Vtot; vb += G * S16) {
@@ -551,7 +576,8 @@ __device__ void process_cell_global(TileShared &sh, const NbArgs &A, int lx, int
     const int f = tile_halo_index(lx + 1, ly + 1, lz + 1);
     const int ncell = uniform_i(sh.fc[f]);
     const int cstart = uniform_i(sh.fs[f]);
-    const int per = (ncell + NB_WAVES - 1) / NB_WAVES; // the four waves share the targets
+    constexpr int NB_WAVES = (FORCE ? NB_FTHREADS : NB_DTHREADS) / 64;
+    const int per = (ncell + NB_WAVES - 1) / NB_WAVES; // the waves share the targets
     const int t0 = w * per, t1 = min(ncell, t0 + per);
     for (int tb = t0; tb < t1; tb += 64) {
         const int T = min(64, t1 - tb);
@@ -607,26 +633,46 @@ __device__ void process_cell_global(TileShared &sh, const NbArgs &A, int lx, int
 
 // ------------------------------------------------------------------------------------------
 template <bool FORCE, bool COUNT>
-__global__ __launch_bounds__(NB_THREADS) void k_neighbors(NbArgs A)
+__global__ __launch_bounds__(FORCE ? NB_FTHREADS : NB_DTHREADS) void k_neighbors(NbArgs A)
 {
     __shared__ TileShared sh;
     __shared__ float4 recP[(FORCE ? NB_FCAP : NB_DCAP) + 1]; // x, y, z, m_j (+ the FAR record)
     __shared__ float4 recV[FORCE ? NB_FCAP + 1 : 1];         // vx, vy, vz, q_j = p_j/rho_j^2
+    __shared__ float tthr[COUNT ? NB_TCAP : 1]; // COUNT variants: exact predicate threshold (h2 / thrF)
 
     const int tile = blockIdx.x;
     const int2 trange = A.ttable[tile];
     if (trange.y <= trange.x) return; // no fluid particle in this tile
     tile_lookup(sh, tile, A);
 
-    if (process_block<FORCE, COUNT>(sh, recP, recV, A, 0, 0, 0, SPH_TX, SPH_TY, SPH_TZ)) return;
-    for (int sb = 0; sb < 8; sb++) { // 2x2x1 sub-blocks
-        const int bx = (sb & 1) * 2, by = ((sb >> 1) & 1) * 2, bz = sb >> 2;
-        if (process_block<FORCE, COUNT>(sh, recP, recV, A, bx, by, bz, 2, 2, 1)) continue;
-        for (int c = 0; c < 4; c++) { // single cells
-            const int lx = bx + (c & 1), ly = by + (c >> 1);
-            if (process_block<FORCE, COUNT>(sh, recP, recV, A, lx, ly, bz, 1, 1, 1)) continue;
-            process_cell_global<FORCE, COUNT>(sh, A, lx, ly, bz);
-            __syncthreads();
+    // The largest block whose 27-cell halo fits the LDS tile: the whole tile, then halves
+    // (4x4x1, 4x2x1, 2x2x1) down to single cells, then straight from global memory.  The 32
+    // cells are numbered so that every block is an aligned run: n = z*16 + (y/2)*8 + (x/2)*4 +
+    // (y&1)*2 + (x&1).
+    // (the whole-tile attempt is a call of its own so that its shape is a compile-time constant)
+    if (process_block<FORCE, COUNT, SPH_TX, SPH_TY, SPH_TZ>(sh, recP, recV, tthr, A, 0, 0, 0)) return;
+    int cursor = 0, size = SPH_TCELLS / 2;
+    while (cursor < SPH_TCELLS) {
+        const int bx = ((cursor >> 2) & 1) * 2 + (cursor & 1), by = ((cursor >> 3) & 1) * 2 + ((cursor >> 1) & 1),
+                  bz = cursor >> 4;
+        bool ok; // one instantiation per shape: the shape is a compile-time constant in each
+        switch (size) {
+        case 16: ok = process_block<FORCE, COUNT, 4, 4, 1>(sh, recP, recV, tthr, A, bx, by, bz); break;
+        case 8: ok = process_block<FORCE, COUNT, 4, 2, 1>(sh, recP, recV, tthr, A, bx, by, bz); break;
+        case 4: ok = process_block<FORCE, COUNT, 2, 2, 1>(sh, recP, recV, tthr, A, bx, by, bz); break;
+        default: ok = process_block<FORCE, COUNT, 1, 1, 1>(sh, recP, recV, tthr, A, bx, by, bz); break;
         }
+        if (ok) {
+            cursor += size;
+        } else if (size > 1) {
+            size = size == 4 ? 1 : size >> 1;
+            continue;
+        } else {
+            process_cell_global<FORCE, COUNT>(sh, A, bx, by, bz);
+            __syncthreads();
+            cursor += 1;
+        }
+        const int low = cursor & -cursor; // largest aligned block at the new cursor
+        size = low >= 16 ? 16 : low >= 8 ? 8 : low >= 4 ? 4 : 1;
     }
 }

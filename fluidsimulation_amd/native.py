@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsphfluid.so")
+# SPHFLUID_LIB selects an experimental build of the same ABI (kernel tuning only)
+LIB_PATH = os.environ.get("SPHFLUID_LIB") or os.path.join(_HERE, "libsphfluid.so")
 
 SPH_OK = 0
 SPH_E_INVALID, SPH_E_NOMEM, SPH_E_DEVICE, SPH_E_NODEVICE, SPH_E_TOOLARGE = -1, -2, -3, -4, -5
