@@ -904,9 +904,9 @@ int sph_compute_density_and_pressure(SphCtx *c, const SphParams *p)
     NbArgs A = neighbor_args(c, p, NB_DCAP);
     if (c->debug & SPH_DEBUG_COUNTS) {
         A.counts = c->dcount.p;
-        k_neighbors<false, true><<<c->grid.tiles, NB_DTHREADS, 0, c->stream>>>(A);
+        k_neighbors<false, true><<<(c->grid.tiles + 7) / 8 * 8, NB_DTHREADS, 0, c->stream>>>(A);
     } else {
-        k_neighbors<false, false><<<c->grid.tiles, NB_DTHREADS, 0, c->stream>>>(A);
+        k_neighbors<false, false><<<(c->grid.tiles + 7) / 8 * 8, NB_DTHREADS, 0, c->stream>>>(A);
     }
     HIPCHK(c, hipGetLastError());
     c->haveDensity = true;
@@ -922,9 +922,9 @@ int sph_compute_force(SphCtx *c, const SphParams *p)
     NbArgs A = neighbor_args(c, p, NB_FCAP);
     if (c->debug & SPH_DEBUG_COUNTS) {
         A.counts = c->fcount.p;
-        k_neighbors<true, true><<<c->grid.tiles, NB_FTHREADS, 0, c->stream>>>(A);
+        k_neighbors<true, true><<<(c->grid.tiles + 7) / 8 * 8, NB_FTHREADS, 0, c->stream>>>(A);
     } else {
-        k_neighbors<true, false><<<c->grid.tiles, NB_FTHREADS, 0, c->stream>>>(A);
+        k_neighbors<true, false><<<(c->grid.tiles + 7) / 8 * 8, NB_FTHREADS, 0, c->stream>>>(A);
     }
     HIPCHK(c, hipGetLastError());
     c->haveForce = true;

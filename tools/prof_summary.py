@@ -23,11 +23,30 @@ def short(name):
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("== kernel-trace stats:", os.path.relpath(f, out))
     rows = list(csv.DictReader(open(f)))
-    print(f"{'kernel':22s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+    print(f"{'kernel':34s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
     for r in rows:
-        print(f"{short(r['Name']):22s} {r['Calls']:>7s} {float(r['TotalDurationNs'])/1e6:10.3f} "
+        print(f"{short(r['Name']):34s} {r['Calls']:>7s} {float(r['TotalDurationNs'])/1e6:10.3f} "
               f"{float(r['AverageNs'])/1e3:10.1f} {float(r['MinNs'])/1e3:10.1f} "
               f"{float(r['MaxNs'])/1e3:10.1f} {float(r['Percentage']):6.2f}")
+
+# the same trace restricted to the timed region of bench.py: the last steps/(steps+warmup) of each
+# kernel's launches (the warm-up steps are launched first)
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if steps:
+    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        per = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        print(f"== timed region only (last {steps} of {steps + warm} steps):", os.path.relpath(f, out))
+        print(f"{'kernel':34s} {'calls':>7s} {'avg_us':>10s} {'ms/step':>10s}")
+        for k, v in sorted(per.items(), key=lambda kv: -sum(e - s for s, e in kv[1])):
+            v.sort()
+            if len(v) % (steps + warm):
+                continue  # not a per-step kernel
+            keep = v[len(v) * warm // (steps + warm):]
+            tot = sum(e - s for s, e in keep)
+            print(f"{k:34s} {len(keep):7d} {tot / len(keep) / 1e3:10.1f} {tot / steps / 1e6:10.3f}")
 
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     if not os.path.isdir(d):
@@ -42,4 +61,4 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
         print("== PMC per launch (mean):", os.path.relpath(f, out))
         for k in acc:
             s = " ".join(f"{c}={acc[k][c]/cnt[k][c]:.4g}" for c in sorted(acc[k]))
-            print(f"{k:22s} n={max(cnt[k].values()):4d} {s}")
+            print(f"{k:34s} n={max(cnt[k].values()):4d} {s}")
