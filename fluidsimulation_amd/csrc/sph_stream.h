@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_reorder(
         if (t == s) continue;
         const int rel = t - blockBase;
         const uint32_t idt = (rel >= 0 && rel < 256) ? ids[rel] : oidIn[perm[t]];
-        rank += idt < id;
+        rank += (idt & 0x3fffffffu) < (id & 0x3fffffffu); // bits 30/31: slab flags (sph_slab.h)
     }
     const int dst = cell.x + rank;
     posmOut[dst] = posmIn[c];

@@ -20,6 +20,7 @@
 #include "sph_neighbors.h"
 #include "sph_sort.h"
 #include "sph_stream.h"
+#include "sph_slab.h"
 
 static_assert(sizeof(SphParticle) == 16, "FluidParticleComponent layout");
 static_assert(sizeof(SphBoundaryParticle) == 12, "BoundaryParticleComponent layout");
@@ -80,6 +81,7 @@ struct SphCtx {
     uint32_t *sortedVals = nullptr;
     bool haveKeys = false, haveSort = false, haveTable = false, ordered = false;
     bool haveDensity = false, haveForce = false;
+    bool rhoInOrder = false; // rho[] lines up with the current particle arrays
 
     // materials
     std::vector<MatKey> matKeys;
@@ -106,6 +108,7 @@ struct SphCtx {
 
     // colliders
     int nboxes = 0;
+    bool anyDynamicBox = false;
     DevBuf<float> boxState;
     DevBuf<DevBox> devBoxes;
     DevBuf<float> bodyImpulse;
@@ -113,6 +116,14 @@ struct SphCtx {
     // sort scratch
     DevBuf<uint32_t> hist, rowTotal;
     DevBuf<float> partial;
+
+    // slab decomposition (sph_slab_*)
+    bool slab = false;
+    int slabCap = 0;    // particle capacity of the fluid buffers
+    int nOwned = 0;     // particles this rank owns
+    int nGhost = 0;     // live ghost records in [0, n)
+    int nDead = 0;      // dead records in [0, n), cut off by the next sort
+    DevBuf<uint32_t> slabCounters;
 
     // timings
     bool timing = false;
@@ -666,6 +677,11 @@ int sph_set_colliders(SphCtx *c, const SphBox *boxes, int32_t K)
     if (K > 65536) return fail(c, SPH_E_TOOLARGE, "at most 65536 box colliders");
     HIPCHK(c, hipSetDevice(c->device));
     c->nboxes = K;
+    c->anyDynamicBox = false;
+    for (int k = 0; k < K; k++)
+        c->anyDynamicBox = c->anyDynamicBox || boxes[k].invMass != 0.f ||
+                           boxes[k].invInertia[0] != 0.f || boxes[k].invInertia[1] != 0.f ||
+                           boxes[k].invInertia[2] != 0.f;
     if (K == 0) return SPH_OK;
     int rc = ensure(c, c->boxState, (size_t)25 * K);
     if (!rc) rc = ensure(c, c->devBoxes, (size_t)K);
@@ -744,6 +760,8 @@ int sph_upload(SphCtx *c, const float *pos, const float *vel, const float *invMa
     if (rc) return rc;
     c->n = N;
     c->cur = 0;
+    c->slab = false;
+    c->nOwned = c->nGhost = c->nDead = 0;
     HIPCHK(c, hipMemcpyAsync(c->io3a.p, pos, (size_t)12 * N, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->io3b.p, vel, (size_t)12 * N, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->ioU.p, c->hostMatIdx.data(), (size_t)4 * N, hipMemcpyHostToDevice,
@@ -770,6 +788,7 @@ int sph_download(SphCtx *c, float *pos_out, float *vel_out)
 {
     if (!c) return SPH_E_INVALID;
     if (c->n <= 0) return fail(c, SPH_E_INVALID, "no particles uploaded");
+    if (c->slab) return fail(c, SPH_E_INVALID, "slab mode: use sph_slab_download");
     const int N = c->n;
     int rc = ensure(c, c->io3a, (size_t)3 * N);
     if (!rc) rc = ensure(c, c->io3b, (size_t)3 * N);
@@ -800,7 +819,10 @@ int sph_hash_position(SphCtx *c, const SphParams *p)
     if (rc) return rc;
     StageTimer t(c, SPH_T_KEYS);
     const int N = c->n, cur = c->cur;
-    if (c->debug & SPH_DEBUG_HASHES)
+    if (c->slab)
+        k_slab_keys<<<blocks_for(N, 256), 256, 0, c->stream>>>(c->posm[cur].p, c->oid[cur].p, N,
+                                                               c->grid, c->keysA.p);
+    else if (c->debug & SPH_DEBUG_HASHES)
         k_keys<true><<<blocks_for(N, 256), 256, 0, c->stream>>>(c->posm[cur].p, c->oid[cur].p, N,
                                                                 c->grid, c->keysA.p, c->hashes.p,
                                                                 c->cells.p, c->keysEcs.p);
@@ -819,9 +841,15 @@ int sph_radix_sort(SphCtx *c)
     if (!c) return SPH_E_INVALID;
     if (!c->haveKeys) return fail(c, SPH_E_INVALID, "sph_radix_sort before sph_hash_position");
     StageTimer t(c, SPH_T_SORT);
+    // slab mode: dead ghosts carry key = cells, sort to the end and are cut off here
     int rc = radix_sort(c, c->keysA.p, c->valsA.p, c->keysB.p, c->valsB.p, c->n,
-                        key_bits(c->grid.cells), &c->sortedKeys, &c->sortedVals);
+                        key_bits(c->grid.cells + (c->slab ? 1 : 0)), &c->sortedKeys,
+                        &c->sortedVals);
     if (rc) return rc;
+    if (c->slab) {
+        c->n -= c->nDead;
+        c->nDead = 0;
+    }
     c->haveSort = true;
     c->haveKeys = false; // keysA may have been overwritten
     c->haveTable = c->ordered = false;
@@ -862,6 +890,7 @@ int sph_reorder(SphCtx *c)
     c->cur = nxt;
     c->ordered = true;
     c->haveDensity = c->haveForce = false;
+    c->rhoInOrder = false;
     return SPH_OK;
 }
 
@@ -910,6 +939,7 @@ int sph_compute_density_and_pressure(SphCtx *c, const SphParams *p)
     }
     HIPCHK(c, hipGetLastError());
     c->haveDensity = true;
+    c->rhoInOrder = true;
     return SPH_OK;
 }
 
@@ -1206,6 +1236,176 @@ int sph_reset_timings(SphCtx *c)
     int rc = collect_timings(c);
     if (rc) return rc;
     std::memset(&c->tm, 0, sizeof(c->tm));
+    return SPH_OK;
+}
+
+// ---- slab decomposition across GPUs ------------------------------------------
+int sph_slab_upload(SphCtx *c, const float *pos, const float *vel, const uint32_t *materialIndex,
+                    const uint32_t *ids, int32_t N, const float *materials, int32_t M,
+                    float gridSize, int32_t capacity)
+{
+    if (!c) return SPH_E_INVALID;
+    if (N < 0 || (N > 0 && (!pos || !vel || !materialIndex || !ids)) || !materials || M <= 0)
+        return fail(c, SPH_E_INVALID, "sph_slab_upload: bad arrays");
+    if (capacity < std::max(N, 1)) return fail(c, SPH_E_INVALID, "capacity below N");
+    if (!(gridSize > 0.f) || !std::isfinite(gridSize))
+        return fail(c, SPH_E_INVALID, "gridSize must be positive and finite");
+    if (c->anyDynamicBox)
+        return fail(c, SPH_E_INVALID, "slab mode supports static colliders only");
+    for (int i = 0; i < N; i++) {
+        if (materialIndex[i] >= (uint32_t)M) return fail(c, SPH_E_INVALID, "material index out of range");
+        if (ids[i] > SPH_ID_MASK) return fail(c, SPH_E_TOOLARGE, "particle ids are limited to 30 bits");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_fluid(c, capacity);
+    if (!rc) rc = ensure(c, c->io3a, (size_t)3 * std::max(N, 1));
+    if (!rc) rc = ensure(c, c->io3b, (size_t)3 * std::max(N, 1));
+    if (!rc) rc = ensure(c, c->ioU, (size_t)2 * std::max(N, 1));
+    if (!rc) rc = ensure(c, c->slabCounters, 4, false);
+    if (rc) return rc;
+    // the material table is the caller's, in the caller's order (the same on every rank)
+    c->matKeys.clear();
+    c->matIndex.clear();
+    for (int m = 0; m < M; m++) {
+        MatKey k;
+        std::memcpy(k.w, materials + 5 * (size_t)m, 20); // radius, rho0, mu, k, invMass
+        c->matKeys.push_back(k);
+    }
+    rc = upload_mats(c, c->matRate > 0.f ? c->matRate : 4.0f);
+    if (rc) return rc;
+    c->slab = true;
+    c->slabCap = capacity;
+    c->n = N;
+    c->nOwned = N;
+    c->nGhost = c->nDead = 0;
+    c->cur = 0;
+    if (N > 0) {
+        HIPCHK(c, hipMemcpyAsync(c->io3a.p, pos, (size_t)12 * N, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->io3b.p, vel, (size_t)12 * N, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->ioU.p, materialIndex, (size_t)4 * N, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->ioU.p + N, ids, (size_t)4 * N, hipMemcpyHostToDevice, c->stream));
+        k_slab_pack_fluid<<<blocks_for(N, 256), 256, 0, c->stream>>>(
+            c->io3a.p, c->io3b.p, c->ioU.p, c->ioU.p + N, c->dmats.p, N, c->posm[0].p,
+            c->velq[0].p, c->mat[0].p, c->oid[0].p);
+        HIPCHK(c, hipGetLastError());
+    }
+    c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
+    c->haveDensity = c->haveForce = false;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->gridExplicit) {
+        // the table must be the same on every rank only in cell size; its extent is local
+        if (N > 0) {
+            rc = auto_grid(c, gridSize);
+            if (rc) return rc;
+        } else {
+            const int o[3] = {0, 0, 0}, d[3] = {64, 64, 64};
+            set_grid(c, o, d, gridSize);
+        }
+    } else {
+        const int o[3] = {c->grid.ox, c->grid.oy, c->grid.oz};
+        const int d[3] = {c->grid.gx, c->grid.gy, c->grid.gz};
+        set_grid(c, o, d, gridSize);
+    }
+    return SPH_OK;
+}
+
+int sph_slab_pack(SphCtx *c, float xlo, float xhi, float halo, void *left_dev, void *right_dev,
+                  int32_t capRecords, int32_t counts[4])
+{
+    if (!c || !counts) return SPH_E_INVALID;
+    if (!c->slab) return fail(c, SPH_E_INVALID, "sph_slab_pack before sph_slab_upload");
+    if (capRecords < 0 || (capRecords > 0 && (!left_dev || !right_dev)))
+        return fail(c, SPH_E_INVALID, "sph_slab_pack: bad buffers");
+    if (!(halo >= 0.f) || !(xlo <= xhi)) return fail(c, SPH_E_INVALID, "sph_slab_pack: bad slab");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->slabCounters.p, 0, 16, c->stream));
+    const int cur = c->cur;
+    if (c->n > 0)
+        k_slab_pack<<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
+            (float4 *)left_dev, (float4 *)right_dev, capRecords, c->slabCounters.p);
+    HIPCHK(c, hipGetLastError());
+    uint32_t h[4];
+    HIPCHK(c, hipMemcpyAsync(h, c->slabCounters.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 4; i++) counts[i] = (int32_t)h[i];
+    // last step's ghosts are dead now; the particles that left stay as this step's ghosts
+    const int moved = (int)(h[2] + h[3]);
+    c->nDead += c->nGhost;
+    c->nGhost = moved;
+    c->nOwned -= moved;
+    if (h[0] > (uint32_t)capRecords || h[1] > (uint32_t)capRecords)
+        return fail(c, SPH_E_TOOLARGE, "exchange buffer too small: %u / %u records, capacity %d",
+                    h[0], h[1], capRecords);
+    return SPH_OK;
+}
+
+int sph_slab_import(SphCtx *c, const void *records_dev, int32_t count, int32_t transfers)
+{
+    if (!c) return SPH_E_INVALID;
+    if (!c->slab) return fail(c, SPH_E_INVALID, "sph_slab_import before sph_slab_upload");
+    if (count < 0 || transfers < 0 || transfers > count || (count > 0 && !records_dev))
+        return fail(c, SPH_E_INVALID, "sph_slab_import: bad arguments");
+    if (count == 0) return SPH_OK;
+    if ((long long)c->n + count > c->slabCap)
+        return fail(c, SPH_E_TOOLARGE, "slab capacity %d exceeded (%d + %d records)", c->slabCap,
+                    c->n, count);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int cur = c->cur, n = c->n;
+    k_slab_import<<<blocks_for(count, 256), 256, 0, c->stream>>>(
+        (const float4 *)records_dev, count, c->dmats.p, (int)c->mats.size(), c->posm[cur].p + n,
+        c->velq[cur].p + n, c->mat[cur].p + n, c->oid[cur].p + n);
+    HIPCHK(c, hipGetLastError());
+    c->rhoInOrder = false;
+    c->n += count;
+    c->nOwned += transfers;
+    c->nGhost += count - transfers;
+    c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
+    c->haveDensity = c->haveForce = false;
+    return SPH_OK;
+}
+
+int sph_slab_counts(SphCtx *c, int32_t counts[4])
+{
+    if (!c || !counts) return SPH_E_INVALID;
+    counts[0] = c->n;
+    counts[1] = c->nOwned;
+    counts[2] = c->nGhost;
+    counts[3] = c->nDead;
+    return SPH_OK;
+}
+
+int sph_slab_download(SphCtx *c, float *pos_out, float *vel_out, float *density_out,
+                      uint32_t *ids_out, int32_t cap, int32_t *count)
+{
+    if (!c || !count) return SPH_E_INVALID;
+    if (!c->slab) return fail(c, SPH_E_INVALID, "sph_slab_download before sph_slab_upload");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = c->n, cur = c->cur;
+    std::vector<float4> hp((size_t)n), hv((size_t)n);
+    std::vector<uint32_t> hid((size_t)n);
+    std::vector<float> hr((size_t)n);
+    if (n > 0) {
+        HIPCHK(c, hipMemcpyAsync(hp.data(), c->posm[cur].p, (size_t)16 * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hv.data(), c->velq[cur].p, (size_t)16 * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hid.data(), c->oid[cur].p, (size_t)4 * n, hipMemcpyDeviceToHost, c->stream));
+        if (density_out && c->rhoInOrder)
+            HIPCHK(c, hipMemcpyAsync(hr.data(), c->rho.p, (size_t)4 * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+        if (hid[i] & (SPH_ID_GHOST | SPH_ID_DEAD)) continue;
+        if (k < cap) {
+            if (pos_out) { pos_out[3 * k] = hp[i].x; pos_out[3 * k + 1] = hp[i].y; pos_out[3 * k + 2] = hp[i].z; }
+            if (vel_out) { vel_out[3 * k] = hv[i].x; vel_out[3 * k + 1] = hv[i].y; vel_out[3 * k + 2] = hv[i].z; }
+            if (density_out) density_out[k] = c->rhoInOrder ? hr[i] : 0.f;
+            if (ids_out) ids_out[k] = hid[i] & SPH_ID_MASK;
+        }
+        k++;
+    }
+    *count = k;
+    if (k > cap) return fail(c, SPH_E_TOOLARGE, "%d owned particles, room for %d", k, cap);
     return SPH_OK;
 }
 

@@ -36,6 +36,7 @@ EXPORTS = [
     "sph_compute_density_and_pressure", "sph_compute_force", "sph_apply_force", "sph_integrate",
     "sph_step_resident", "sph_step", "sph_step_compat", "sph_read", "sph_find_bounds",
     "sph_sort_pairs", "sph_get_timings", "sph_reset_timings",
+    "sph_slab_upload", "sph_slab_pack", "sph_slab_import", "sph_slab_counts", "sph_slab_download",
 ]
 
 
@@ -108,6 +109,11 @@ def load():
     lib.sph_find_bounds.argtypes = [vp, f32, vp, vp]
     lib.sph_sort_pairs.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.sph_get_timings.argtypes = [vp, C.POINTER(SphTimings)]
+    lib.sph_slab_upload.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, f32, i32]
+    lib.sph_slab_pack.argtypes = [vp, f32, f32, f32, vp, vp, i32, C.POINTER(i32 * 4)]
+    lib.sph_slab_import.argtypes = [vp, vp, i32, i32]
+    lib.sph_slab_counts.argtypes = [vp, C.POINTER(i32 * 4)]
+    lib.sph_slab_download.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(i32)]
     for name in EXPORTS:
         if name not in ("sph_last_error", "sph_find_grid_size"):
             getattr(lib, name).restype = C.c_int
@@ -329,6 +335,43 @@ class Context:
 
     def reset_timings(self):
         self._chk(self.lib.sph_reset_timings(self.h))
+
+    # -- slab decomposition (device pointers are plain integers, e.g. torch.Tensor.data_ptr())
+    def slab_upload(self, pos, vel, material_index, ids, materials, grid_size, capacity):
+        pos, vel = _f32(pos, (-1, 3)), _f32(vel, (-1, 3))
+        mi = np.ascontiguousarray(material_index, dtype=np.uint32)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        mats = _f32(materials, (-1, 5))
+        self.n = len(pos)
+        assert len(vel) == self.n and len(mi) == self.n and len(ids) == self.n
+        self._chk(self.lib.sph_slab_upload(self.h, _ptr(pos), _ptr(vel), _ptr(mi), _ptr(ids),
+                                           self.n, _ptr(mats), len(mats), grid_size, capacity))
+
+    def slab_pack(self, xlo, xhi, halo, left_ptr, right_ptr, cap_records):
+        counts = (C.c_int32 * 4)()
+        self._chk(self.lib.sph_slab_pack(self.h, xlo, xhi, halo, left_ptr, right_ptr, cap_records,
+                                         C.byref(counts)))
+        return list(counts)
+
+    def slab_import(self, records_ptr, count, transfers):
+        self._chk(self.lib.sph_slab_import(self.h, records_ptr, count, transfers))
+
+    def slab_counts(self):
+        counts = (C.c_int32 * 4)()
+        self._chk(self.lib.sph_slab_counts(self.h, C.byref(counts)))
+        return dict(zip(("resident", "owned", "ghosts", "dead"), counts))
+
+    def slab_download(self):
+        cap = self.slab_counts()["resident"]
+        pos = np.empty((cap, 3), np.float32)
+        vel = np.empty((cap, 3), np.float32)
+        rho = np.empty(cap, np.float32)
+        ids = np.empty(cap, np.uint32)
+        k = C.c_int32()
+        self._chk(self.lib.sph_slab_download(self.h, _ptr(pos), _ptr(vel), _ptr(rho), _ptr(ids),
+                                             cap, C.byref(k)))
+        k = k.value
+        return pos[:k], vel[:k], rho[:k], ids[:k]
 
 
 def find_grid_size(params, chunk_first, rate=4.0):

@@ -224,6 +224,47 @@ SPH_API int sph_sort_pairs(SphCtx *ctx, const uint32_t *keys, int32_t n, int32_t
 SPH_API int sph_get_timings(SphCtx *ctx, SphTimings *out); /* synchronises */
 SPH_API int sph_reset_timings(SphCtx *ctx);
 
+/* ---- slab decomposition across GPUs --------------------------------------------------------
+ * No counterpart in the reference (its solver runs on one device, FluidSPHByGPUSystem.cs:59-68);
+ * this is SURVEY.md section 8(e): one process per GPU, every rank owns the fluid particles with
+ * x in [xlo, xhi) and trades, once per step, with its two x neighbours.  The library packs and
+ * unpacks DEVICE buffers; moving them between ranks (RCCL send/recv) is the caller's part
+ * (fluidsimulation_amd/slab.py).  Exchange record, 32 bytes:
+ *     float pos[3]; uint32 material; float vel[3]; uint32 id;
+ * id bit 31 set = ghost copy (the sender keeps the particle), clear = ownership transfer.
+ * Ghosts live for exactly one step (they are cut off by the next step's sort), so the halo must
+ * be 2 h: a ghost within h of the face then has all of its own neighbours present and its
+ * density, which the force pass needs, is computed locally.
+ *
+ * Per step: sph_slab_pack -> exchange -> sph_slab_import (each neighbour) -> sph_step_resident.
+ * Static box colliders only (dynamic bodies would need their impulses summed over ranks). */
+
+/* Like sph_upload, with global particle ids (< 2^30, unique over all ranks) and an explicit
+ * material table that must be identical on every rank: materials[5*m] = radius, restDensity,
+ * viscosity, gasConstant, inverseMass; materialIndex[i] < M.  capacity = the most records
+ * (owned + ghosts of two consecutive steps) the fluid buffers have to hold. */
+SPH_API int sph_slab_upload(SphCtx *ctx, const float *pos, const float *vel,
+                            const uint32_t *materialIndex, const uint32_t *ids, int32_t N,
+                            const float *materials, int32_t M, float gridSize, int32_t capacity);
+/* Marks last step's ghosts dead and fills the two DEVICE buffers (capRecords records each):
+ * left  <- owned particles with x < xlo + halo (x < xlo: transfer, the local copy stays as a
+ * ghost for this step), right <- x >= xhi - halo (x >= xhi: transfer).  Pass -INF / +INF on
+ * the outer ranks.  counts = records left, records right, transfers left, transfers right.
+ * The order of the records is not deterministic; the order of the particles after the next sort
+ * is (cell, id).  Synchronises. */
+SPH_API int sph_slab_pack(SphCtx *ctx, float xlo, float xhi, float halo, void *left_dev,
+                          void *right_dev, int32_t capRecords, int32_t counts[4]);
+/* Appends `count` records from a DEVICE buffer; `transfers` of them carry no ghost bit (the
+ * sender's counts[2] or counts[3]).  Asynchronous on the context's stream. */
+SPH_API int sph_slab_import(SphCtx *ctx, const void *records_dev, int32_t count,
+                            int32_t transfers);
+/* counts = records resident, owned, live ghosts, dead ghosts */
+SPH_API int sph_slab_counts(SphCtx *ctx, int32_t counts[4]);
+/* the owned particles, host arrays, in the resident order; density_out is zero-filled unless a
+ * density pass has run since the last reorder.  cap = room in particles. */
+SPH_API int sph_slab_download(SphCtx *ctx, float *pos_out, float *vel_out, float *density_out,
+                              uint32_t *ids_out, int32_t cap, int32_t *count);
+
 #ifdef __cplusplus
 }
 #endif
