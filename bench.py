@@ -63,15 +63,60 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        # SPH_BENCH_COMM=gloo rehearses the multi-rank path on fewer GPUs than ranks
+        comm = os.environ.get("SPH_BENCH_COMM", "nccl")
+        ngpu = torch.cuda.device_count()
+        local = local % max(ngpu, 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if comm == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(comm)
 
-    sc = scene.make_config(a.config, jittered=True)
-    p = native.make_params(sc.grid_size, body_bounds=(sc.tank_min, sc.tank_max))
-    ctx = native.Context(device=local, timings=True)
-    ctx.set_boundary(sc.bpos, sc.bparams)
-    ctx.set_colliders(sc.boxes)
-    ctx.upload(sc.pos, sc.vel, sc.inv_mass, sc.params, sc.grid_size)
+    sim = None
+    if world == 1:
+        sc = scene.make_config(a.config, jittered=True)
+        p = native.make_params(sc.grid_size, body_bounds=(sc.tank_min, sc.tank_max))
+        ctx = native.Context(device=local, timings=True)
+        ctx.set_boundary(sc.bpos, sc.bparams)
+        ctx.set_colliders(sc.boxes)
+        ctx.upload(sc.pos, sc.vel, sc.inv_mass, sc.params, sc.grid_size)
+        n_local = sc.n
+        parallelism = "1 gpu"
+        workload = (f"{a.config} dam break: {sc.n} fluid + {sc.b} boundary particles + "
+                    f"{len(sc.boxes)} box colliders, dt=1/60, h=1.0, jitter 0.02")
+    else:
+        # weak scaling: every rank owns one --config sized block of a dam break that is `world`
+        # blocks wide in x and flows along z (every x column carries the same flow, so the slabs
+        # stay balanced); x-slab decomposition, halo 2 h, RCCL send/recv of device buffers
+        from fluidsimulation_amd import slab
+        nx, ny, nz, ci = scene.CONFIGS[a.config]
+        sc, ids = scene.dam_break_slab(nx * world, ny, nz, rank * nx, (rank + 1) * nx,
+                                       jitter_seed=scene.JITTER_SEED_BASE + ci, name=a.config)
+        p = native.make_params(sc.grid_size, body_bounds=(sc.tank_min, sc.tank_max))
+        sp = 2.0 * float(scene.RADIUS)
+        edges = [-np.inf] + [r * nx * sp for r in range(1, world)] + [np.inf]
+        table, index = slab.material_table(sc.inv_mass, sc.params)
+        ctx = native.Context(device=local, timings=True)
+        ctx.set_boundary(sc.bpos, sc.bparams)
+        ctx.set_colliders(sc.boxes)
+        face = ny * nz * 4            # lattice sites within the 2 h halo of one face
+        ctx.slab_upload(sc.pos, sc.vel, index, ids, table, sc.grid_size,
+                        capacity=sc.n + 16 * face)
+        be = slab.HipSlabBackend(ctx, p, f"cuda:{local}", buffer_records=4 * face)
+        sim = slab.SlabSimulation(be, edges, halo=2.0 * sc.grid_size)
+        n_local = sc.n
+        parallelism = (f"x-slab decomposition over {world} ranks, ghosts within 2h + ownership "
+                       f"transfers by {dist.get_backend()} send/recv every step")
+        workload = (f"{world} x {a.config} block dam break along z: {sc.n} fluid particles per "
+                    f"GPU ({world * sc.n} total), {sc.b} boundary particles + {len(sc.boxes)} "
+                    f"static boxes per rank, dt=1/60, h=1.0, jitter 0.02")
+
+    def run(nsteps):
+        if sim is None:
+            ctx.step_resident(p, nsteps)
+        else:
+            sim.step(nsteps)
 
     def barrier():
         ctx.synchronize()
@@ -80,25 +125,38 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    ctx.step_resident(p, a.warmup)
+    run(a.warmup)
     barrier()
     ctx.reset_timings()
     t0 = time.perf_counter()
-    ctx.step_resident(p, a.steps)
+    run(a.steps)
     ctx.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tm = ctx.timings()
-    pos, vel = ctx.download()
+    if sim is None:
+        pos, vel = ctx.download()
+        slab_info = None
+    else:
+        pos, vel, _, _ = ctx.slab_download()
+        slab_info = dict(ctx.slab_counts(), sent_records_per_step=sim.sent_records //
+                         max(a.steps + a.warmup, 1), transfers_out=sim.transfers_out)
     finite = bool(np.isfinite(pos).all() and np.isfinite(vel).all())
+    if dist is not None:
+        import torch
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        f = torch.tensor([1 if finite else 0], device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        finite = bool(f.item())
 
     if rank == 0:
-        n = sc.n
+        n = n_local
         ms_step = elapsed / a.steps * 1e3
         stage_ms = {k: tm["ms"][k] / max(tm["steps"], 1) for k in tm["ms"]}
         _, _, key_bits, _ = ctx.get_grid()
@@ -112,10 +170,7 @@ def main():
             "unit": "particle-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.config} dam break: {n} fluid + {sc.b} boundary particles "
-                                   f"+ {len(sc.boxes)} box colliders per GPU, dt=1/60, h=1.0, "
-                                   f"jitter 0.02", "particles_per_gpu": n,
-                       "parallelism": "independent tanks, one per GPU" if world > 1 else "1 gpu"},
+            "config": {"workload": workload, "particles_per_gpu": n, "parallelism": parallelism},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None,
@@ -126,7 +181,9 @@ def main():
                               "frac": step_alg * n / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "stage_ms": stage_ms, "finite": finite,
         }
-        if not a.no_cpu_baseline:
+        if slab_info is not None:
+            out["slab_rank0"] = slab_info
+        if not a.no_cpu_baseline and world == 1:
             bsc = sc if not a.cpu_baseline_config else scene.make_config(a.cpu_baseline_config)
             out["cpu_baseline"] = cpu_baseline(bsc, a.cpu_baseline_config or a.config)
         print(json.dumps(out))

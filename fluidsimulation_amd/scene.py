@@ -223,6 +223,77 @@ def dam_break(nx, ny, nz, jitter_seed=None, origin=(0.0, 0.0, 0.0), name=""):
                  tank_min=org.copy(), tank_max=org + L, name=name)
 
 
+def splitmix64_at(index, seed):
+    """splitmix64_uniform's value number `index` (0-based), for arbitrary index arrays."""
+    g = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + ((np.asarray(index, np.uint64) + np.uint64(1)) * g)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(F32)
+
+
+def dam_break_slab(nx, ny, nz, col0, col1, jitter_seed=None, margin_cols=8, amplitude=0.02,
+                   name=""):
+    """The columns col0 <= x-index < col1 of a dam break that runs along z: the fluid block
+    nx*ny*nz (spacing 0.5) fills the first third of a tank of interior (nx, ny, 3nz)*0.5.  Used
+    for the x-slab decomposition: every x column carries the same flow, so the slabs stay
+    balanced.  Returns (Scene, global ids); ids and jitter depend only on the global lattice
+    index, so any partition of the columns gives the same particles.  The boundary layers are
+    cut to the columns within margin_cols of the slab; the wall boxes are the whole tank's."""
+    sp = F32(2) * RADIUS
+    xs = np.arange(col0, col1, dtype=np.int64)
+    zz, yy, xx = np.meshgrid(np.arange(nz, dtype=np.int64), np.arange(ny, dtype=np.int64), xs,
+                             indexing="ij")
+    gid = ((zz * ny + yy) * nx + xx).ravel()
+    pos = np.stack([(xx.ravel().astype(F32) + F32(0.5)) * sp,
+                    (yy.ravel().astype(F32) + F32(0.5)) * sp,
+                    (zz.ravel().astype(F32) + F32(0.5)) * sp], axis=1).astype(F32)
+    if jitter_seed is not None:
+        idx3 = (gid[:, None] * 3 + np.arange(3, dtype=np.int64)[None, :])
+        u = splitmix64_at(idx3, jitter_seed)
+        pos = (pos + (u * F32(2) - F32(1)) * F32(amplitude)).astype(F32)
+    tx, ty, tz = nx, ny, 3 * nz
+    L = np.array([tx, ty, tz], F32) * sp
+    b0, b1 = max(0, col0 - margin_cols), min(tx, col1 + margin_cols)
+    bx = (np.arange(b0, b1, dtype=F32) + F32(0.5)) * sp
+
+    def plane_xu(nu, fixed_axis, fixed_value):   # spans x (cut) and one other axis
+        other = 2 if fixed_axis == 1 else 1
+        u = (np.arange(nu, dtype=F32) + F32(0.5)) * sp
+        uu, xg = np.meshgrid(u, bx, indexing="ij")
+        pts = np.empty((uu.size, 3), F32)
+        pts[:, 0] = xg.ravel()
+        pts[:, other] = uu.ravel()
+        pts[:, fixed_axis] = fixed_value
+        return pts
+
+    faces = [plane_xu(tz, 1, F32(0)), plane_xu(tz, 1, L[1]),
+             plane_xu(ty, 2, F32(0)), plane_xu(ty, 2, L[2])]
+    if b0 == 0:
+        faces.append(_plane(ty, tz, 0, F32(0), sp))
+    if b1 == tx:
+        faces.append(_plane(ty, tz, 0, L[0], sp))
+    bpos = np.concatenate(faces, axis=0)
+    half = L * F32(0.5)
+    t = F32(0.25)
+    boxes = []
+    for a in range(3):
+        for side in (0, 1):
+            c = half.copy()
+            c[a] = L[a] + t if side else -t
+            he = half.copy() + F32(2) * t
+            he[a] = t
+            boxes.append(static_box(c, he))
+    params, inv_mass = _fluid_arrays(len(pos))
+    sc = Scene(pos=pos, vel=np.zeros_like(pos), inv_mass=inv_mass, params=params, bpos=bpos,
+               bparams=_boundary_params(len(bpos)), grid_size=float(RADIUS * KERNEL_RADIUS_RATE),
+               boxes=np.stack(boxes).astype(F32), tank_min=np.zeros(3, F32), tank_max=L,
+               name=name)
+    return sc, gid.astype(np.uint32)
+
+
 CONFIGS = {
     # name: (nx, ny, nz, config index for the jitter seed)
     "C1": (12, 20, 20, 0),
