@@ -54,6 +54,20 @@ def cpu_baseline(sc, name):
                       f"{dt:.2f} s"}
 
 
+def measured_traffic(kernel, config, n):
+    """HBM bytes per launch from the committed PMC profile (profiles/hbm_traffic.json), or None
+    when there is no measurement for this kernel and workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            t = json.load(f)
+        if t["config"] != config or t["n"] != n or kernel not in t:
+            return None
+        k = t[kernel]
+        return (2.0 * k["fetch_size_kb"] + k["write_size_kb"]) * 1024.0
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,7 +187,9 @@ def main():
             "config": {"workload": workload, "particles_per_gpu": n, "parallelism": parallelism},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": measured_traffic(dom, a.config, n) if world == 1 else None,
+                         "limiter": "fp32 VALU issue (SQ_INSTS_VALU x 4 cycles = 88-99 % of the "
+                                    "kernel's SIMD cycles, profiles/), not HBM",
                          "alg_bytes_per_particle": alg[dom],
                          "avg_launch_ms": stage_ms[dom]},
             "step_roofline": {"alg_bytes_per_particle_step": step_alg,
