@@ -166,16 +166,19 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
     float4 *__restrict__ posm, float4 *__restrict__ velq, const float4 *__restrict__ force,
     const float *__restrict__ rho, const uint32_t *__restrict__ mat,
     const Mat *__restrict__ mats, int n, float dt, const DevBox *__restrict__ boxes, int nboxes,
-    float particleRestitution, float *__restrict__ bodyImpulse)
+    float particleRestitution, float *__restrict__ bodyImpulse,
+    const uint32_t *__restrict__ slabFlags /* slab mode: ids with the ghost bit, else nullptr */)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), vv = pv;
     Mat m = mats[0];
+    bool owned = true; // a ghost's push on a body is counted by the rank that owns the particle
     if (live) {
         pv = posm[i];
         vv = velq[i];
         m = mats[mat[i]];
+        if (slabFlags) owned = (slabFlags[i] & 0x80000000u) == 0;
     }
     float x[3] = {pv.x, pv.y, pv.z}, v[3] = {vv.x, vv.y, vv.z};
     if (APPLY && live) {
@@ -275,10 +278,10 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
 #pragma unroll
                             for (int a = 0; a < 3; a++) {
                                 v[a] = v[a] + jp * nw[a];
-                                imp[a] = -(j * nw[a]);
-                                imp[3 + a] = -(j * rxn[a]);
+                                imp[a] = owned ? -(j * nw[a]) : 0.f;
+                                imp[3 + a] = owned ? -(j * rxn[a]) : 0.f;
                             }
-                            pushed = true;
+                            pushed = owned;
                         }
                     }
                 }

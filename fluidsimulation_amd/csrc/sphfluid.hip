@@ -968,7 +968,8 @@ static int launch_apply_integrate(SphCtx *c, const SphParams *p, bool apply, boo
 #define LAUNCH_AI(A, I)                                                                          \
     k_apply_integrate<A, I><<<nb, 256, 0, c->stream>>>(                                          \
         c->posm[cur].p, c->velq[cur].p, c->force.p, c->rho.p, c->mat[cur].p, c->dmats.p, N,      \
-        p->dt, c->devBoxes.p, c->nboxes, p->particleRestitution, c->bodyImpulse.p)
+        p->dt, c->devBoxes.p, c->nboxes, p->particleRestitution, c->bodyImpulse.p,               \
+        c->slab ? c->oid[cur].p : nullptr)
     if (apply && integrate) LAUNCH_AI(true, true);
     else if (apply) LAUNCH_AI(true, false);
     else LAUNCH_AI(false, true);
@@ -1018,6 +1019,9 @@ int sph_step_resident(SphCtx *c, const SphParams *p, int32_t nsteps)
     int rc = check_params(c, p);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->slab && c->anyDynamicBox)
+        return fail(c, SPH_E_INVALID, "slab mode with dynamic boxes: use sph_slab_step_particles, "
+                                      "sum the impulses over ranks, sph_slab_step_bodies");
     for (int s = 0; s < nsteps; s++) {
         if ((rc = sph_hash_position(c, p))) return rc;
         if ((rc = sph_radix_sort(c))) return rc;
@@ -1250,8 +1254,6 @@ int sph_slab_upload(SphCtx *c, const float *pos, const float *vel, const uint32_
     if (capacity < std::max(N, 1)) return fail(c, SPH_E_INVALID, "capacity below N");
     if (!(gridSize > 0.f) || !std::isfinite(gridSize))
         return fail(c, SPH_E_INVALID, "gridSize must be positive and finite");
-    if (c->anyDynamicBox)
-        return fail(c, SPH_E_INVALID, "slab mode supports static colliders only");
     for (int i = 0; i < N; i++) {
         if (materialIndex[i] >= (uint32_t)M) return fail(c, SPH_E_INVALID, "material index out of range");
         if (ids[i] > SPH_ID_MASK) return fail(c, SPH_E_TOOLARGE, "particle ids are limited to 30 bits");
@@ -1362,6 +1364,56 @@ int sph_slab_import(SphCtx *c, const void *records_dev, int32_t count, int32_t t
     c->nGhost += count - transfers;
     c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
     c->haveDensity = c->haveForce = false;
+    return SPH_OK;
+}
+
+int sph_slab_step_particles(SphCtx *c, const SphParams *p)
+{
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (!c->slab) return fail(c, SPH_E_INVALID, "sph_slab_step_particles before sph_slab_upload");
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = sph_hash_position(c, p))) return rc;
+    if ((rc = sph_radix_sort(c))) return rc;
+    if ((rc = sph_map_table(c))) return rc;
+    if ((rc = sph_reorder(c))) return rc;
+    if ((rc = sph_compute_density_and_pressure(c, p))) return rc;
+    if ((rc = sph_compute_force(c, p))) return rc;
+    {
+        StageTimer t(c, SPH_T_INTEGRATE);
+        if ((rc = launch_apply_integrate(c, p, true, true))) return rc;
+    }
+    c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
+    c->haveDensity = c->haveForce = false;
+    c->tm.steps++;
+    return SPH_OK;
+}
+
+int sph_slab_get_impulses(SphCtx *c, float *impulses_out, int32_t K)
+{
+    if (!c || (K > 0 && !impulses_out)) return SPH_E_INVALID;
+    if (K != c->nboxes) return fail(c, SPH_E_INVALID, "K != number of colliders");
+    if (K == 0) return SPH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(impulses_out, c->bodyImpulse.p, sizeof(float) * 6 * (size_t)K,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_slab_step_bodies(SphCtx *c, const SphParams *p, const float *impulses, int32_t K)
+{
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (K != c->nboxes) return fail(c, SPH_E_INVALID, "K != number of colliders");
+    if (K == 0) return SPH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (impulses)
+        HIPCHK(c, hipMemcpyAsync(c->bodyImpulse.p, impulses, sizeof(float) * 6 * (size_t)K,
+                                 hipMemcpyHostToDevice, c->stream));
+    rc = launch_bodies(c, p);
+    if (rc) return rc;
+    if (impulses) HIPCHK(c, hipStreamSynchronize(c->stream)); // the host array may go away
     return SPH_OK;
 }
 

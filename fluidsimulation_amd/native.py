@@ -37,6 +37,7 @@ EXPORTS = [
     "sph_step_resident", "sph_step", "sph_step_compat", "sph_read", "sph_find_bounds",
     "sph_sort_pairs", "sph_get_timings", "sph_reset_timings",
     "sph_slab_upload", "sph_slab_pack", "sph_slab_import", "sph_slab_counts", "sph_slab_download",
+    "sph_slab_step_particles", "sph_slab_get_impulses", "sph_slab_step_bodies",
 ]
 
 
@@ -113,6 +114,9 @@ def load():
     lib.sph_slab_pack.argtypes = [vp, f32, f32, f32, vp, vp, i32, C.POINTER(i32 * 4)]
     lib.sph_slab_import.argtypes = [vp, vp, i32, i32]
     lib.sph_slab_counts.argtypes = [vp, C.POINTER(i32 * 4)]
+    lib.sph_slab_step_particles.argtypes = [vp, C.POINTER(SphParams)]
+    lib.sph_slab_get_impulses.argtypes = [vp, vp, i32]
+    lib.sph_slab_step_bodies.argtypes = [vp, C.POINTER(SphParams), vp, i32]
     lib.sph_slab_download.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(i32)]
     for name in EXPORTS:
         if name not in ("sph_last_error", "sph_find_grid_size"):
@@ -355,6 +359,18 @@ class Context:
 
     def slab_import(self, records_ptr, count, transfers):
         self._chk(self.lib.sph_slab_import(self.h, records_ptr, count, transfers))
+
+    def slab_step_particles(self, p):
+        self._chk(self.lib.sph_slab_step_particles(self.h, C.byref(p)))
+
+    def slab_get_impulses(self):
+        out = np.zeros((self.nboxes, 6), np.float32)
+        self._chk(self.lib.sph_slab_get_impulses(self.h, _ptr(out), self.nboxes))
+        return out
+
+    def slab_step_bodies(self, p, impulses=None):
+        imp = None if impulses is None else _f32(impulses, (-1, 6))
+        self._chk(self.lib.sph_slab_step_bodies(self.h, C.byref(p), _ptr(imp), self.nboxes))
 
     def slab_counts(self):
         counts = (C.c_int32 * 4)()

@@ -63,9 +63,10 @@ def uniform_edges(xmin, xmax, world):
 class HipSlabBackend:
     """The product backend: libsphfluid (HIP) with torch tensors as exchange buffers."""
 
-    def __init__(self, ctx, params, device, buffer_records):
+    def __init__(self, ctx, params, device, buffer_records, dynamic_bodies=False):
         self.ctx = ctx
         self.params = params
+        self.dynamic_bodies = bool(dynamic_bodies)
         self.device = torch.device(device)
         self.cap = int(buffer_records)
         self.left = torch.empty((self.cap, RECORD_FLOATS), dtype=torch.float32, device=self.device)
@@ -87,6 +88,16 @@ class HipSlabBackend:
 
     def step(self):
         self.ctx.step_resident(self.params, 1)
+
+    # with dynamic boxes the step is split around the sum of the body impulses over ranks
+    def step_particles(self):
+        self.ctx.slab_step_particles(self.params)
+
+    def get_impulses(self):
+        return self.ctx.slab_get_impulses()
+
+    def step_bodies(self, impulses):
+        self.ctx.slab_step_bodies(self.params, impulses)
 
     def synchronize(self):
         self.ctx.synchronize()
@@ -170,7 +181,18 @@ class SlabSimulation:
         for _ in range(nsteps):
             if self.world > 1:
                 self.exchange()
-            self.backend.step()
+            if getattr(self.backend, "dynamic_bodies", False):
+                # replicated rigid bodies: every rank needs the pushes of all ranks' particles;
+                # the one collective of the step, K*6 floats
+                self.backend.step_particles()
+                imp = torch.from_numpy(np.ascontiguousarray(self.backend.get_impulses()))
+                if self.world > 1:
+                    if not self.stage_on_host:
+                        imp = imp.to(self.backend.device)
+                    dist.all_reduce(imp, op=dist.ReduceOp.SUM, group=self.group)
+                self.backend.step_bodies(imp.cpu().numpy())
+            else:
+                self.backend.step()
 
 
 def split_scene(scene, edges, rank, margin):

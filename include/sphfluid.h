@@ -237,7 +237,10 @@ SPH_API int sph_reset_timings(SphCtx *ctx);
  * density, which the force pass needs, is computed locally.
  *
  * Per step: sph_slab_pack -> exchange -> sph_slab_import (each neighbour) -> sph_step_resident.
- * Static box colliders only (dynamic bodies would need their impulses summed over ranks). */
+ * Box colliders are replicated on every rank.  With dynamic boxes the step is split so that the
+ * pushes of all ranks' particles reach every copy of a body: sph_slab_step_particles ->
+ * sph_slab_get_impulses -> sum over ranks (one all-reduce of K*6 floats, the caller's) ->
+ * sph_slab_step_bodies.  Ghosts never push a body (their owner's rank counts them). */
 
 /* Like sph_upload, with global particle ids (< 2^30, unique over all ranks) and an explicit
  * material table that must be identical on every rank: materials[5*m] = radius, restDensity,
@@ -258,6 +261,12 @@ SPH_API int sph_slab_pack(SphCtx *ctx, float xlo, float xhi, float halo, void *l
  * sender's counts[2] or counts[3]).  Asynchronous on the context's stream. */
 SPH_API int sph_slab_import(SphCtx *ctx, const void *records_dev, int32_t count,
                             int32_t transfers);
+/* one step without the rigid bodies' update / the bodies' update with the summed impulses
+ * (linear xyz, angular xyz per box; NULL = this rank's own) */
+SPH_API int sph_slab_step_particles(SphCtx *ctx, const SphParams *p);
+SPH_API int sph_slab_get_impulses(SphCtx *ctx, float *impulses_out /* K*6 */, int32_t K);
+SPH_API int sph_slab_step_bodies(SphCtx *ctx, const SphParams *p, const float *impulses /* K*6 */,
+                                 int32_t K);
 /* counts = records resident, owned, live ghosts, dead ghosts */
 SPH_API int sph_slab_counts(SphCtx *ctx, int32_t counts[4]);
 /* the owned particles, host arrays, in the resident order; density_out is zero-filled unless a

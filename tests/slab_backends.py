@@ -22,6 +22,8 @@ class NumpySlabBackend:
         self.bpos, self.bparams = bpos, bparams
         self.grid, self.boxes, self.dt = grid_size, boxes, dt
         self.rho = np.zeros(len(self.pos), np.float32)
+        self.boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, scene.BOX_FLOATS).copy()
+        self.dynamic_bodies = bool(np.any(self.boxes[:, 16:20] != 0))
         self.transfers_out = 0
         self.transfers_in = 0
 
@@ -63,14 +65,27 @@ class NumpySlabBackend:
         self.mat = np.concatenate([self.mat, np.ascontiguousarray(rec[:, 3]).view(np.uint32)])
         self.ids = np.concatenate([self.ids, ids])
 
-    def step(self):
+    def step_particles(self):
         m = self.materials[self.mat]
         params, inv_mass = np.ascontiguousarray(m[:, 0:4]), np.ascontiguousarray(m[:, 4])
         vel, dens, _, _ = self.o.sph_step(self.pos, self.vel, inv_mass, params, self.bpos,
                                           self.bparams, self.grid, dt=self.dt)
+        own = (self.ids & ID_GHOST) == 0   # ghosts do not push the bodies
+        _, _, self.impulses = self.o.integrate_particles(self.pos[own], vel[own], inv_mass[own],
+                                                         params[own], self.boxes, self.dt)
         self.pos, self.vel, _ = self.o.integrate_particles(self.pos, vel, inv_mass, params,
                                                            self.boxes, self.dt)
         self.rho = dens
+
+    def get_impulses(self):
+        return self.impulses
+
+    def step_bodies(self, impulses):
+        self.boxes = self.o.integrate_bodies(self.boxes, impulses, self.dt)
+
+    def step(self):
+        self.step_particles()
+        self.step_bodies(self.impulses)
 
     def synchronize(self):
         pass

@@ -1,5 +1,5 @@
 """One rank of a slab-decomposition test; launched by tests/test_slab.py under
-torch.distributed.run (gloo).  argv: backend ("numpy" | "hip") nsteps out_json
+torch.distributed.run (gloo).  argv: backend ("numpy" | "hip") nsteps out_json bodies(0|1)
 
 Every rank builds the same small dam-break scene, keeps its slab, runs nsteps with
 SlabSimulation and sends its owned particles to rank 0, which compares them, by particle id,
@@ -19,8 +19,12 @@ sys.path.insert(0, ROOT)
 from fluidsimulation_amd import scene, slab  # noqa: E402
 
 
-def build_scene():
+def build_scene(bodies):
     sc = scene.dam_break(16, 10, 10, jitter_seed=0x51AB)
+    if bodies:
+        # a rigid box dipped into the fluid across the future slab face: both ranks push it
+        box = scene.dynamic_box((4.0, 4.6, 2.5), (1.0, 0.5, 1.0), 2000.0)
+        sc.boxes = np.concatenate([sc.boxes, box[None, :]]).astype(np.float32)
     # a shear across the future slab face so that particles change owner within a few steps
     mid = 0.5 * (sc.pos[:, 0].min() + sc.pos[:, 0].max())
     sc.vel[:, 0] = np.where(sc.pos[:, 2] > np.median(sc.pos[:, 2]), 6.0, -6.0).astype(np.float32)
@@ -29,9 +33,10 @@ def build_scene():
 
 def main():
     backend_name, nsteps, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    bodies = len(sys.argv) > 4 and sys.argv[4] == "1"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    sc, mid = build_scene()
+    sc, mid = build_scene(bodies)
     h = sc.grid_size
     span = sc.pos[:, 0].max() - sc.pos[:, 0].min()
     edges = [-np.inf] + [float(sc.pos[:, 0].min() + span * r / world) for r in range(1, world)] \
@@ -54,7 +59,7 @@ def main():
         ctx.slab_upload(sc.pos[own], sc.vel[own], index, ids, table, sc.grid_size,
                         capacity=2 * sc.n)
         be = slab.HipSlabBackend(ctx, native.make_params(sc.grid_size), "cuda:0",
-                                 buffer_records=sc.n)
+                                 buffer_records=sc.n, dynamic_bodies=bodies)
     sim = slab.SlabSimulation(be, edges, halo=2.0 * h)
     history = []
     for _ in range(nsteps):
@@ -63,7 +68,8 @@ def main():
     be.synchronize()
     pos, vel, rho, pid = be.download()
     gathered = [None] * world
-    dist.gather_object((pos, vel, rho, pid, history, sim.sent_records, sim.transfers_out), gathered if rank == 0 else None)
+    my_boxes = be.boxes if backend_name == "numpy" else be.ctx.get_colliders()
+    dist.gather_object((pos, vel, rho, pid, history, sim.sent_records, sim.transfers_out, my_boxes), gathered if rank == 0 else None)
     if rank == 0:
         allpos = np.concatenate([g[0] for g in gathered])
         allvel = np.concatenate([g[1] for g in gathered])
@@ -81,12 +87,13 @@ def main():
             # the undecomposed run
             if backend_name == "numpy":
                 from oracle import oracle as O
-                rpos, rvel = sc.pos.copy(), sc.vel.copy()
+                rpos, rvel, rboxes = sc.pos.copy(), sc.vel.copy(), sc.boxes.copy()
                 for _ in range(nsteps):
                     rvel, rrho, _, _ = O.sph_step(rpos, rvel, sc.inv_mass, sc.params, sc.bpos,
                                                   sc.bparams, sc.grid_size, dt=float(scene.DT))
-                    rpos, rvel, _ = O.integrate_particles(rpos, rvel, sc.inv_mass, sc.params,
-                                                          static_boxes, float(scene.DT))
+                    rpos, rvel, rimp = O.integrate_particles(rpos, rvel, sc.inv_mass, sc.params,
+                                                             rboxes, float(scene.DT))
+                    rboxes = O.integrate_bodies(rboxes, rimp, float(scene.DT))
             else:
                 from fluidsimulation_amd import native
                 ref = native.Context(device=0)
@@ -100,6 +107,7 @@ def main():
                 rrho = ref.read(native.SPH_BUF_DENSITIES)
                 ref.compute_force(p); ref.apply_force(p); ref.integrate(p)
                 rpos, rvel = ref.download()
+                rboxes = ref.get_colliders()
                 ref.close()
             scale_p = float(np.abs(rpos).max())
             scale_v = float(np.abs(rvel).max())
@@ -107,6 +115,9 @@ def main():
             verdict["max_vel_err"] = float(np.abs(gvel - rvel).max() / scale_v)
             verdict["max_rho_err"] = float(np.abs(grho - rrho).max() / float(np.abs(rrho).max()))
             verdict["moved_owner"] = int(sum(g[6] for g in gathered))
+            bscale = float(np.abs(rboxes).max())
+            verdict["max_body_err"] = float(max(np.abs(g[7] - rboxes).max() for g in gathered) / bscale)
+            verdict["body_moved"] = float(np.abs(rboxes - sc.boxes).max())
         verdict["ok"] = bool(ok)
         with open(out_path, "w") as f:
             json.dump(verdict, f)
