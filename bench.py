@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="C3", choices=list(scene.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-round-trip", action="store_true")
     ap.add_argument("--cpu-baseline-config", default=None,
                     help="workload of the bounded CPU sample (default: same as --config)")
     return ap.parse_args()
@@ -199,6 +200,18 @@ def main():
         }
         if slab_info is not None:
             out["slab_rank0"] = slab_info
+        if world == 1 and not a.no_host_round_trip:
+            # the span FluidSPHByGPUSystem.cs:227-252 pays every frame: upload, step, download of
+            # caller-owned host arrays (pageable memory) -- reported beside `value`, never as it
+            hp, hv = pos.copy(), vel.copy()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                hp, hv, _, _ = ctx.step(p, hp, hv, sc.inv_mass, sc.params)
+            rt = (time.perf_counter() - t1) / 3
+            out["host_round_trip"] = {"ms_per_step": rt * 1e3, "value": n / rt,
+                                      "unit": "particle-updates/s",
+                                      "what": "sph_step: upload 44 B + step + download 24 B per "
+                                              "particle, 3 frames"}
         if not a.no_cpu_baseline and world == 1:
             bsc = sc if not a.cpu_baseline_config else scene.make_config(a.cpu_baseline_config)
             out["cpu_baseline"] = cpu_baseline(bsc, a.cpu_baseline_config or a.config)

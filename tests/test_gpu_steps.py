@@ -206,11 +206,13 @@ def test_error_paths(ctx):
         ctx.hash_position(bad)
 
 
-def test_one_million_particle_properties(ctx, oracle):
-    """C2 (1 M particles): size-independent properties -- the permutation is a permutation and
-    sorted by key; the table partitions [0, N); densities of a sampled slab equal the oracle's
-    on that slab's neighbourhood; momentum change equals the summed force * dt / rho * ..."""
-    sc = scene.make_config("C2")
+@pytest.mark.parametrize("config", ["C2", "C3"])
+def test_full_size_properties(ctx, oracle, config):
+    """C2 (1 M) and C3 (16.7 M particles, the size the metric is quoted on): size-independent
+    properties -- the permutation is a permutation, sorted by key with ties by id; the table
+    partitions [0, N); densities and forces of a sampled slab equal the oracle's computed on
+    that slab's neighbourhood."""
+    sc = scene.make_config(config)
     p = load_scene(ctx, sc, debug=native.SPH_DEBUG_HASHES)
     ctx.hash_position(p)
     keys = ctx.read(native.SPH_BUF_KEYS)
