@@ -42,9 +42,10 @@ if steps:
         print(f"{'kernel':34s} {'calls':>7s} {'avg_us':>10s} {'ms/step':>10s}")
         for k, v in sorted(per.items(), key=lambda kv: -sum(e - s for s, e in kv[1])):
             v.sort()
-            if len(v) % (steps + warm):
+            m = len(v) // (steps + warm)   # launches per step; a few extra launches may follow
+            if m == 0 or len(v) - m * (steps + warm) > 8 * m:
                 continue  # not a per-step kernel
-            keep = v[len(v) * warm // (steps + warm):]
+            keep = v[m * warm:m * (warm + steps)]
             tot = sum(e - s for s, e in keep)
             print(f"{k:34s} {len(keep):7d} {tot / len(keep) / 1e3:10.1f} {tot / steps / 1e6:10.3f}")
 
