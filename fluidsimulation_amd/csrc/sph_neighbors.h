@@ -53,10 +53,10 @@
 #define NB_FG 4 // same, force
 #endif
 #ifndef NB_DCAP
-#define NB_DCAP 1536 // LDS records per block, density kernel (24 KB): four workgroups per CU
+#define NB_DCAP 1728 // LDS records per block, density kernel (27 KB): four workgroups per CU
 #endif
 #ifndef NB_FCAP
-#define NB_FCAP 1216 // LDS records per block, force kernel (2 x 19 KB): three workgroups per CU
+#define NB_FCAP 1280 // LDS records per block, force kernel (2 x 20 KB): three workgroups per CU
 #endif
 #define NB_TCAP 512  // targets per block whose constants are cached in LDS
 

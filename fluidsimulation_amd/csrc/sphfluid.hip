@@ -1131,6 +1131,9 @@ int sph_read(SphCtx *c, int32_t buffer, void *out, size_t bytes)
 {
     if (!c || !out) return SPH_E_INVALID;
     if (c->n <= 0) return fail(c, SPH_E_INVALID, "no particles uploaded");
+    if (c->slab) // ids are global there, not indices into the caller's arrays
+        return fail(c, SPH_E_INVALID, "slab mode: the ECS-ordered views are not available "
+                                      "(sph_slab_download returns the owned particles)");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t N = (size_t)c->n;
     const void *src = nullptr;
