@@ -77,6 +77,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own HIP/HSA runtime.  A process that uses both must load torch's copy
+    # first: loaded after libsphfluid's, it finds no device ("No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not built: run __graft_entry__.build() "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")

@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import pytest
+import torch  # noqa: F401  (before libsphfluid: see fluidsimulation_amd/native.py load())
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -68,3 +69,65 @@ def test_slab_rigid_body_on_the_gpu(tmp_path):
     v = run_ranks("hip", 2, 4, tmp_path, bodies=True)
     check(v, 1e-5)
     check_bodies(v)
+
+
+def test_slab_scene_is_partition_independent():
+    """dam_break_slab: ids and jittered positions depend only on the global lattice index, so any
+    split of the x columns yields the same particles (what lets every rank build its own slab)"""
+    import numpy as np
+    from fluidsimulation_amd import scene
+    whole, wid = scene.dam_break_slab(16, 6, 5, 0, 16, jitter_seed=5)
+    by_id = dict(zip(wid.tolist(), map(tuple, whole.pos.tolist())))
+    assert len(by_id) == whole.n == 16 * 6 * 5
+    seen = 0
+    for lo, hi in ((0, 5), (5, 12), (12, 16)):
+        part, pid = scene.dam_break_slab(16, 6, 5, lo, hi, jitter_seed=5)
+        assert all(by_id[k] == tuple(v) for k, v in zip(pid.tolist(), part.pos.tolist()))
+        assert np.all((part.pos[:, 0] >= lo * 0.5 - 0.02) & (part.pos[:, 0] < hi * 0.5 + 0.02))
+        seen += part.n
+    assert seen == whole.n
+
+
+def test_material_table_is_sorted_union():
+    import numpy as np
+    from fluidsimulation_amd import slab
+    params = np.array([[0.25, 1000, 256, 512]] * 3 + [[0.25, 800, 256, 512]] * 2, np.float32)
+    inv_mass = np.full(5, 1 / 125, np.float32)
+    table, index = slab.material_table(inv_mass, params)
+    assert table.shape == (2, 5) and index.tolist() in ([0, 0, 0, 1, 1], [1, 1, 1, 0, 0])
+    assert np.array_equal(table[index][:, :4], params)
+
+
+@pytest.mark.gpu
+def test_slab_error_paths():
+    import numpy as np
+    from fluidsimulation_amd import native, scene
+    sc = scene.dam_break(4, 4, 4)
+    ctx = native.Context(device=0)
+    with pytest.raises(native.SphError):           # pack before upload
+        ctx.slab_pack(0.0, 1.0, 2.0, 0, 0, 0)
+    mats = np.array([[0.25, 1000, 256, 512, 1 / 125]], np.float32)
+    idx = np.zeros(sc.n, np.uint32)
+    ids = np.arange(sc.n, dtype=np.uint32)
+    with pytest.raises(native.SphError):           # capacity below N
+        ctx.slab_upload(sc.pos, sc.vel, idx, ids, mats, sc.grid_size, capacity=sc.n - 1)
+    with pytest.raises(native.SphError):           # material index out of range
+        ctx.slab_upload(sc.pos, sc.vel, idx + 1, ids, mats, sc.grid_size, capacity=2 * sc.n)
+    ctx.slab_upload(sc.pos, sc.vel, idx, ids, mats, sc.grid_size, capacity=sc.n + 4)
+    assert ctx.slab_counts() == {"resident": sc.n, "owned": sc.n, "ghosts": 0, "dead": 0}
+    with pytest.raises(native.SphError):           # ECS-ordered views are refused in slab mode
+        ctx.download()
+    import torch
+    rec = torch.zeros((8, 8), dtype=torch.float32, device="cuda:0")
+    with pytest.raises(native.SphError):           # more records than the capacity holds
+        ctx.slab_import(rec.data_ptr(), 8, 0)
+    # everything within the halo of an open-ended slab: nothing to send, nothing moves
+    assert ctx.slab_pack(-np.inf, np.inf, 2.0, rec.data_ptr(), rec.data_ptr(), 8) == [0, 0, 0, 0]
+    p = native.make_params(sc.grid_size)
+    ctx.step_resident(p, 2)
+    pos, vel, rho, pid = ctx.slab_download()
+    assert len(pid) == sc.n and np.array_equal(np.sort(pid), ids) and np.isfinite(pos).all()
+    ctx.upload(sc.pos, sc.vel, sc.inv_mass, sc.params, sc.grid_size)   # leaves slab mode
+    ctx.step_resident(p, 1)
+    ctx.download()
+    ctx.close()
