@@ -20,6 +20,34 @@ __global__ void k_pack_fluid(const float *__restrict__ pos3, const float *__rest
     oid[i] = (uint32_t)i;
 }
 
+// FluidInitializeSystem.CreateParticles (FluidInitializeSystem.cs:63-92) on the device: lattice
+// point (ix,iy,iz), x fastest, local = i*2*rad + bounds.Min + rad (:84-86), world =
+// MultiplyPoint3x4(localToWorld, local).  l2w is 3x4 row-major.
+struct SeedDesc {
+    int nx, ny, nz;
+    float rad[3], bmin[3], l2w[12];
+};
+__global__ void k_seed_lattice(SeedDesc d, float mass, uint32_t matIdx, uint32_t idBase, int count,
+                               float4 *__restrict__ posm, float4 *__restrict__ velq,
+                               uint32_t *__restrict__ mat, uint32_t *__restrict__ oid)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int ix = i % d.nx, iy = (i / d.nx) % d.ny, iz = i / (d.nx * d.ny);
+    const float two = 2.0f;
+    const float lx = (float)ix * two * d.rad[0] + d.bmin[0] + d.rad[0];
+    const float ly = (float)iy * two * d.rad[1] + d.bmin[1] + d.rad[1];
+    const float lz = (float)iz * two * d.rad[2] + d.bmin[2] + d.rad[2];
+    float w[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        w[r] = (d.l2w[4 * r] * lx + d.l2w[4 * r + 1] * ly) + d.l2w[4 * r + 2] * lz + d.l2w[4 * r + 3];
+    posm[i] = make_float4(w[0], w[1], w[2], mass);
+    velq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    mat[i] = matIdx;
+    oid[i] = idBase + (uint32_t)i;
+}
+
 __global__ void k_pack_boundary(const float *__restrict__ pos3, const float *__restrict__ bparams,
                                 int n, float4 *__restrict__ bposm)
 {

@@ -458,6 +458,21 @@ int ensure_fluid(SphCtx *c, int n)
     return rc;
 }
 
+// grows the CURRENT fluid arrays to hold n records, keeping their first `keep`
+template <typename T> int grow_keep(SphCtx *c, DevBuf<T> &b, size_t n, size_t keep)
+{
+    if (n <= b.cap && b.p) return SPH_OK;
+    DevBuf<T> nb;
+    int rc = ensure(c, nb, std::max(n, b.cap + b.cap / 2), false);
+    if (rc) return rc;
+    if (keep && b.p)
+        HIPCHK(c, hipMemcpyAsync(nb.p, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    release(b);
+    b = nb;
+    return SPH_OK;
+}
+
 int ensure_debug(SphCtx *c)
 {
     int rc = 0;
@@ -1244,6 +1259,81 @@ int sph_reset_timings(SphCtx *c)
     if (rc) return rc;
     std::memset(&c->tm, 0, sizeof(c->tm));
     return SPH_OK;
+}
+
+int sph_seed_volume(SphCtx *c, const float localToWorld[12], const float boundsMin[3],
+                    const float boundsSize[3], float radius, const SphParticle *params,
+                    float invMass, float gridSize, int32_t append, int32_t *added)
+{
+    if (!c || !localToWorld || !boundsMin || !boundsSize || !params || !added) return SPH_E_INVALID;
+    if (c->slab) return fail(c, SPH_E_INVALID, "sph_seed_volume is not available in slab mode");
+    if (!(radius > 0.f) || !(invMass > 0.f) || !(gridSize > 0.f) || !std::isfinite(gridSize))
+        return fail(c, SPH_E_INVALID, "radius, invMass and gridSize must be positive");
+    SeedDesc d;
+    long long count = 1;
+    int num[3];
+    for (int a = 0; a < 3; a++) {
+        // radius / |localToWorld * axis|  (:65-67), (int)((size + r) / (2 r))  (:69-71)
+        const float x = localToWorld[a], y = localToWorld[4 + a], z = localToWorld[8 + a];
+        volatile float len2 = (x * x + y * y) + z * z;
+        const float len = sqrtf(len2);
+        d.rad[a] = radius / len;
+        d.bmin[a] = boundsMin[a];
+        if (!(d.rad[a] > 0.f) || !std::isfinite(d.rad[a]))
+            return fail(c, SPH_E_INVALID, "degenerate localToWorld");
+        const float q = (boundsSize[a] + d.rad[a]) / (2.0f * d.rad[a]);
+        num[a] = q > 0.f ? (int)std::min(q, 1.0e6f) : 0;
+        count *= num[a];
+    }
+    std::memcpy(d.l2w, localToWorld, sizeof(d.l2w));
+    d.nx = num[0]; d.ny = num[1]; d.nz = num[2];
+    *added = 0;
+    const int base = append ? c->n : 0;
+    if (count <= 0) return SPH_OK;
+    if (base + count > (1ll << 30)) return fail(c, SPH_E_TOOLARGE, "more than 2^30 particles");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int cur = append ? c->cur : 0;
+    const size_t total = (size_t)(base + count);
+    int rc = grow_keep(c, c->posm[cur], total, (size_t)base);
+    if (!rc) rc = grow_keep(c, c->velq[cur], total, (size_t)base);
+    if (!rc) rc = grow_keep(c, c->mat[cur], total, (size_t)base);
+    if (!rc) rc = grow_keep(c, c->oid[cur], total, (size_t)base);
+    if (!rc) rc = ensure_fluid(c, (int)total);
+    if (rc) return rc;
+    // material of the new particles
+    if (!append) {
+        c->matKeys.clear();
+        c->matIndex.clear();
+    }
+    MatKey k;
+    std::memcpy(&k.w[0], params, 16);
+    std::memcpy(&k.w[4], &invMass, 4);
+    uint32_t mi = 0;
+    for (; mi < c->matKeys.size(); mi++)
+        if (c->matKeys[mi] == k) break;
+    if (mi == c->matKeys.size()) c->matKeys.push_back(k);
+    rc = upload_mats(c, c->matRate > 0.f ? c->matRate : 4.0f);
+    if (rc) return rc;
+    k_seed_lattice<<<blocks_for((long)count, 256), 256, 0, c->stream>>>(
+        d, c->mats[mi].mass, mi, (uint32_t)base, (int)count, c->posm[cur].p + base,
+        c->velq[cur].p + base, c->mat[cur].p + base, c->oid[cur].p + base);
+    HIPCHK(c, hipGetLastError());
+    c->n = (int)total;
+    c->cur = cur;
+    c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
+    c->haveDensity = c->haveForce = false;
+    c->rhoInOrder = false;
+    if (c->gridExplicit) {
+        const int o[3] = {c->grid.ox, c->grid.oy, c->grid.oz};
+        const int dd[3] = {c->grid.gx, c->grid.gy, c->grid.gz};
+        set_grid(c, o, dd, gridSize);
+    } else {
+        rc = auto_grid(c, gridSize);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *added = (int32_t)count;
+    return ensure_debug(c);
 }
 
 // ---- slab decomposition across GPUs ------------------------------------------

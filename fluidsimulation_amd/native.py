@@ -32,6 +32,7 @@ EXPORTS = [
     "sph_create", "sph_destroy", "sph_last_error", "sph_device_name", "sph_set_debug",
     "sph_synchronize", "sph_find_grid_size", "sph_set_boundary", "sph_set_colliders",
     "sph_get_colliders", "sph_set_grid", "sph_get_grid", "sph_upload", "sph_download",
+    "sph_seed_volume",
     "sph_hash_position", "sph_radix_sort", "sph_map_table", "sph_reorder",
     "sph_compute_density_and_pressure", "sph_compute_force", "sph_apply_force", "sph_integrate",
     "sph_step_resident", "sph_step", "sph_step_compat", "sph_read", "sph_find_bounds",
@@ -104,6 +105,7 @@ def load():
     lib.sph_get_grid.argtypes = [vp, C.POINTER(SphGrid)]
     lib.sph_upload.argtypes = [vp, vp, vp, vp, vp, i32, f32]
     lib.sph_download.argtypes = [vp, vp, vp]
+    lib.sph_seed_volume.argtypes = [vp, vp, vp, vp, f32, vp, f32, f32, i32, C.POINTER(i32)]
     for name in ("sph_hash_position", "sph_compute_density_and_pressure", "sph_compute_force",
                  "sph_apply_force", "sph_integrate"):
         getattr(lib, name).argtypes = [vp, C.POINTER(SphParams)]
@@ -239,6 +241,18 @@ class Context:
         assert len(vel) == self.n and len(inv_mass) == self.n and len(params) == self.n
         self._chk(self.lib.sph_upload(self.h, _ptr(pos), _ptr(vel), _ptr(inv_mass), _ptr(params),
                                       self.n, grid_size))
+
+    def seed_volume(self, local_to_world, bounds_min, bounds_size, radius, params, inv_mass,
+                    grid_size, append=False):
+        l2w = _f32(local_to_world, (12,))
+        bmin, bsize = _f32(bounds_min, (3,)), _f32(bounds_size, (3,))
+        prm = _f32(params, (4,))
+        added = C.c_int32()
+        self._chk(self.lib.sph_seed_volume(self.h, _ptr(l2w), _ptr(bmin), _ptr(bsize), radius,
+                                           _ptr(prm), inv_mass, grid_size, 1 if append else 0,
+                                           C.byref(added)))
+        self.n = (self.n if append else 0) + added.value
+        return added.value
 
     def download(self):
         pos = np.empty((self.n, 3), np.float32)

@@ -180,6 +180,15 @@ SPH_API int sph_upload(SphCtx *ctx, const float *pos /* N*3 */, const float *vel
                        const float *invMass /* N */, const SphParticle *params /* N */,
                        int32_t N, float gridSize);
 SPH_API int sph_download(SphCtx *ctx, float *pos_out /* N*3 */, float *vel_out /* N*3 */);
+/* FluidInitializeSystem.CreateParticles (FluidInitializeSystem.cs:63-92) on the device, so that a
+ * scene never crosses PCIe: fills the local box [boundsMin, boundsMin +
+ * boundsSize] of an authoring volume with a lattice at spacing 2*radius in world units, x fastest
+ * then y then z, mapped through localToWorld (3x4 row-major, as MultiplyPoint3x4), velocity 0,
+ * every particle with *params / invMass.  append != 0 adds to the resident fluid (ids continue),
+ * else replaces it.  The new particles' ids are [n_before, n_before + *added). */
+SPH_API int sph_seed_volume(SphCtx *ctx, const float localToWorld[12], const float boundsMin[3],
+                            const float boundsSize[3], float radius, const SphParticle *params,
+                            float invMass, float gridSize, int32_t append, int32_t *added);
 
 /* ---- stages on the device-resident state --------------------------------------------------
  * One entry point per dispatch of FluidSPHByGPUSystem.cs:242-247 (same names), plus the two

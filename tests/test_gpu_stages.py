@@ -136,3 +136,39 @@ def test_apply_force_and_integrate(ctx, oracle):
     assert_close(gvel, ovel, what="velocity")
     oboxes = oracle.integrate_bodies(sc.boxes, oimp, float(p.dt))
     assert_close(ctx.get_colliders(), oboxes, what="bodies")
+
+
+def test_seed_volume_matches_create_particles(ctx):
+    """sph_seed_volume = FluidInitializeSystem.CreateParticles (:63-92) on the device: positions
+    bit-exact against the host generator for the demo's water volume and a rotated, scaled wall;
+    a second volume appends with continuing ids"""
+    s = 0.7071068
+    vols = [((-6, 5, 0), (0, 0, 0, 1), (6, 10, 10)),           # water, ConvertedSubScene.unity:666-667
+            ((0, 10, 0), (s, -0.0, -0.0, -s), (20, 10, 0.5))]  # ceiling wall, :139-171
+    prm = np.array([0.25, 1000.0, 256.0, 512.0], np.float32)
+    want = []
+    for k, (pos, rot, scale) in enumerate(vols):
+        w, num = scene.create_particles(pos, rot, scale, scene.RADIUS)
+        want.append(w)
+        l2w = np.zeros((3, 4), np.float32)
+        l2w[:, :3] = scene.quat_matrix(rot) * np.asarray(scale, np.float32)[None, :]
+        l2w[:, 3] = pos
+        added = ctx.seed_volume(l2w, (-0.5, -0.5, -0.5), (1.0, 1.0, 1.0), 0.25, prm, 1.0 / 125.0,
+                                1.0, append=k > 0)
+        assert added == len(w) == num[0] * num[1] * num[2]
+    want = np.concatenate(want)
+    assert ctx.n == len(want) == 4800 + 800
+    gpos, gvel = ctx.download()
+    assert np.array_equal(gpos, want)
+    assert not gvel.any()
+    p = native.make_params(1.0)
+    ctx.step_resident(p, 1)
+    gpos, _ = ctx.download()
+    assert np.isfinite(gpos).all()
+    # seeded state == uploaded state: one step from each gives the same bits
+    with native.Context(device=0) as other:
+        params, inv_mass = scene._fluid_arrays(len(want))
+        other.upload(want, np.zeros_like(want), inv_mass, params, 1.0)
+        other.step_resident(p, 1)
+        opos, _ = other.download()
+    assert np.array_equal(gpos, opos)
