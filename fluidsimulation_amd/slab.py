@@ -60,6 +60,41 @@ def uniform_edges(xmin, xmax, world):
     return e
 
 
+def plan_cuts(edges, counts, halo, max_shift, domain=None):
+    """New cut positions from the owned counts of all ranks (pure; every rank computes the same).
+    Cut f moves by half of what would equalise the counts on its two sides, at most max_shift."""
+    world = len(counts)
+    total = sum(counts)
+    if total == 0:
+        return list(edges)
+    target = total / world
+    lo_dom, hi_dom = domain if domain is not None else (None, None)
+    new = list(edges)
+    for f in range(1, world):
+        excess = sum(counts[:f]) - f * target        # > 0: too many particles left of cut f
+        donor = f - 1 if excess > 0 else f
+        lo, hi = edges[donor], edges[donor + 1]
+        if donor == 0 and lo_dom is not None:
+            lo = lo_dom
+        if donor == world - 1 and hi_dom is not None:
+            hi = hi_dom
+        if not (math.isfinite(lo) and math.isfinite(hi)) or hi <= lo or counts[donor] == 0:
+            continue
+        per_unit = counts[donor] / (hi - lo)            # particles per unit of x in the donor
+        shift = -0.5 * excess / per_unit
+        new[f] = edges[f] + max(-max_shift, min(max_shift, shift))
+    # A rank only talks to its two neighbours, so after the move everything within one halo of
+    # a rank's slab must still be owned (before the exchange) by that rank or a neighbour:
+    # the new cut f stays at least one halo inside the OLD slabs on both of its sides.
+    for f in range(1, world):
+        lo_ok = edges[f - 1] + halo if f > 1 else -math.inf
+        hi_ok = edges[f + 1] - halo if f < world - 1 else math.inf
+        new[f] = edges[f] if lo_ok > hi_ok else min(max(new[f], lo_ok), hi_ok)
+    for f in range(2, world):                           # and the interior slabs >= one halo wide
+        new[f] = max(new[f], new[f - 1] + halo)
+    return new
+
+
 class HipSlabBackend:
     """The product backend: libsphfluid (HIP) with torch tensors as exchange buffers."""
 
@@ -112,20 +147,51 @@ class HipSlabBackend:
 class SlabSimulation:
     """Drives one rank of the decomposition.  backend: pack / import_records / step / download."""
 
-    def __init__(self, backend, edges, halo, rank=None, world=None, group=None):
+    def __init__(self, backend, edges, halo, rank=None, world=None, group=None,
+                 rebalance_every=0, domain=None, max_shift=None):
+        """rebalance_every = k > 0: every k steps the cuts move towards equal particle counts (by
+        at most max_shift, default one halo); domain = (xmin, xmax) of the fluid, used for the
+        width of the two open-ended slabs.  The static boundary particles of a rank must cover
+        its slab plus 3 h (they enter the densities of its ghosts) wherever the cuts may go."""
         self.backend = backend
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         assert len(edges) == self.world + 1
-        self.xlo = float(edges[self.rank]) if self.rank > 0 else -math.inf
-        self.xhi = float(edges[self.rank + 1]) if self.rank < self.world - 1 else math.inf
+        self.edges = [float(e) for e in edges]
         self.halo = float(halo)
+        for r in range(1, self.world - 1):   # neighbour-only exchange: interior slabs >= one halo
+            assert self.edges[r + 1] - self.edges[r] >= self.halo, "slab narrower than the halo"
+        self._set_bounds()
+        self.rebalance_every = int(rebalance_every)
+        self.domain = domain
+        self.max_shift = float(max_shift) if max_shift is not None else self.halo
+        self.steps_done = 0
+        self.owned_history = []
         # gloo moves host memory; nccl (RCCL) moves device memory
         self.stage_on_host = self.world > 1 and dist.get_backend(group) != "nccl"
         self.sent_records = 0
         self.received_records = 0
         self.transfers_out = 0
+
+    def _set_bounds(self):
+        self.xlo = self.edges[self.rank] if self.rank > 0 else -math.inf
+        self.xhi = self.edges[self.rank + 1] if self.rank < self.world - 1 else math.inf
+
+    def rebalance(self):
+        """Moves the interior cuts towards equal owned counts.  Every rank computes the same new
+        cuts from the all-gathered counts; the particles on the wrong side of a moved cut change
+        owner through the ordinary transfer of the next exchange (the sender keeps ghost copies
+        of what it hands over, both sides pack against the new cut, and plan_cuts keeps every
+        rank's needs within reach of its two neighbours).  One all-gather of `world` integers, outside the per-step data path."""
+        dev = torch.device("cpu") if self.stage_on_host else self.backend.device
+        mine = torch.tensor([self.backend.counts()["owned"]], dtype=torch.int64, device=dev)
+        gathered = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(gathered, mine, group=self.group)
+        counts = [int(g.item()) for g in gathered]
+        self.owned_history.append(counts)
+        self.edges = plan_cuts(self.edges, counts, self.halo, self.max_shift, self.domain)
+        self._set_bounds()
 
     def _peer(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
@@ -179,6 +245,10 @@ class SlabSimulation:
 
     def step(self, nsteps=1):
         for _ in range(nsteps):
+            if self.world > 1 and self.rebalance_every > 0 and \
+                    self.steps_done % self.rebalance_every == 0:
+                self.rebalance()
+            self.steps_done += 1
             if self.world > 1:
                 self.exchange()
             if getattr(self.backend, "dynamic_bodies", False):

@@ -34,6 +34,7 @@ def build_scene(bodies):
 def main():
     backend_name, nsteps, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     bodies = len(sys.argv) > 4 and sys.argv[4] == "1"
+    rebalance = len(sys.argv) > 5 and sys.argv[5] == "1"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     sc, mid = build_scene(bodies)
@@ -41,7 +42,12 @@ def main():
     span = sc.pos[:, 0].max() - sc.pos[:, 0].min()
     edges = [-np.inf] + [float(sc.pos[:, 0].min() + span * r / world) for r in range(1, world)] \
         + [np.inf]
-    own, bsel = slab.split_scene(sc, edges, rank, margin=3.0 * h)
+    if rebalance:   # start from badly placed cuts: most of the fluid on rank 0
+        x0 = float(sc.pos[:, 0].min())
+        edges = [-np.inf] + [x0 + 0.60 * span + 2.2 * h * (r - 1) for r in range(1, world)] + [np.inf]
+    # boundary particles within 3 h of the slab (they enter the densities of the ghosts too); with
+    # moving cuts every rank keeps the whole boundary
+    own, bsel = slab.split_scene(sc, edges, rank, margin=(1e9 if rebalance else 3.0 * h))
     table, index = slab.material_table(sc.inv_mass[own], sc.params[own])
     ids = own.astype(np.uint32)
     static_boxes = sc.boxes
@@ -60,7 +66,9 @@ def main():
                         capacity=2 * sc.n)
         be = slab.HipSlabBackend(ctx, native.make_params(sc.grid_size), "cuda:0",
                                  buffer_records=sc.n, dynamic_bodies=bodies)
-    sim = slab.SlabSimulation(be, edges, halo=2.0 * h)
+    sim = slab.SlabSimulation(be, edges, halo=2.0 * h, rebalance_every=1 if rebalance else 0,
+                              domain=(float(sc.pos[:, 0].min()), float(sc.pos[:, 0].max())),
+                              max_shift=1.0 * h)
     history = []
     for _ in range(nsteps):
         sim.step()
@@ -79,7 +87,8 @@ def main():
                    "unique_ids": int(len(np.unique(allid))),
                    "sent_records": [int(g[5]) for g in gathered],
                    "owned_per_rank": [[h_["owned"] for h_ in g[4]] for g in gathered],
-                   "ghosts_per_rank": [[h_["ghosts"] for h_ in g[4]] for g in gathered]}
+                   "ghosts_per_rank": [[h_["ghosts"] for h_ in g[4]] for g in gathered],
+                   "final_edges": [e for e in sim.edges if np.isfinite(e)]}
         ok = verdict["gathered"] == sc.n and verdict["unique_ids"] == sc.n
         if ok:
             order = np.argsort(allid)
@@ -115,6 +124,8 @@ def main():
             verdict["max_vel_err"] = float(np.abs(gvel - rvel).max() / scale_v)
             verdict["max_rho_err"] = float(np.abs(grho - rrho).max() / float(np.abs(rrho).max()))
             verdict["moved_owner"] = int(sum(g[6] for g in gathered))
+            worst = np.argsort(-np.abs(gvel - rvel).max(axis=1))[:5]
+            verdict["worst_particles"] = [[float(v) for v in rpos[i]] + [float(np.abs(gvel[i] - rvel[i]).max())] for i in worst]
             bscale = float(np.abs(rboxes).max())
             verdict["max_body_err"] = float(max(np.abs(g[7] - rboxes).max() for g in gathered) / bscale)
             verdict["body_moved"] = float(np.abs(rboxes - sc.boxes).max())

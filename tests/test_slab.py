@@ -19,12 +19,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_ranks(backend, world, nsteps, tmp_path, bodies=False, timeout=600):
+def run_ranks(backend, world, nsteps, tmp_path, bodies=False, rebalance=False, timeout=600):
     out = tmp_path / f"verdict_{backend}_{world}.json"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port",
            str(free_port()), os.path.join(ROOT, "tests", "slab_worker.py"), backend, str(nsteps),
-           str(out), "1" if bodies else "0"]
+           str(out), "1" if bodies else "0", "1" if rebalance else "0"]
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -56,6 +56,18 @@ def test_slab_rigid_body_impulses_are_summed_over_cpu_ranks(tmp_path):
     v = run_ranks("numpy", 2, 4, tmp_path, bodies=True)
     check(v, 1e-5)
     check_bodies(v)
+
+
+def test_slab_cuts_move_towards_balance_on_cpu_ranks(tmp_path):
+    """cuts that start with most of the fluid on rank 0 move, one halo-limited shift per step,
+    towards equal counts; the run still equals the undecomposed one"""
+    v = run_ranks("numpy", 3, 6, tmp_path, rebalance=True)
+    check(v, 1e-5)
+    owned = v["owned_per_rank"]
+    first = [o[0] for o in owned]
+    last = [o[-1] for o in owned]
+    assert max(first) - min(first) > max(last) - min(last), (first, last)
+    assert last[0] < first[0]
 
 
 @pytest.mark.gpu
@@ -131,3 +143,30 @@ def test_slab_error_paths():
     ctx.step_resident(p, 1)
     ctx.download()
     ctx.close()
+
+
+def test_plan_cuts_is_bounded_and_converges():
+    """plan_cuts: moves towards equal counts, never by more than max_shift, never beyond one halo
+    inside the old neighbouring slabs, interior slabs stay one halo wide"""
+    import math
+    from fluidsimulation_amd.slab import plan_cuts
+    halo, dom = 2.0, (0.0, 40.0)
+    edges = [-math.inf, 30.0, 34.0, math.inf]
+    density = lambda lo, hi: 100.0 * (min(hi, 40.0) - max(lo, 0.0))   # uniform fluid on [0, 40]
+    for _ in range(60):
+        counts = [density(edges[r] if r else 0.0, edges[r + 1] if r < 2 else 40.0) for r in range(3)]
+        new = plan_cuts(edges, counts, halo, 1.5, dom)
+        for f in (1, 2):
+            assert abs(new[f] - edges[f]) <= 1.5 + 1e-9
+        assert new[1] <= edges[2] - halo + 1e-9 and new[2] >= edges[1] + halo - 1e-9
+        assert new[2] - new[1] >= halo - 1e-9
+        edges = new
+    assert abs(edges[1] - 40.0 / 3) < 0.5 and abs(edges[2] - 80.0 / 3) < 0.5
+    assert plan_cuts([-math.inf, 1.0, math.inf], [0, 0], halo, 1.0) == [-math.inf, 1.0, math.inf]
+
+
+@pytest.mark.gpu
+def test_slab_cuts_move_on_the_gpu(tmp_path):
+    v = run_ranks("hip", 2, 5, tmp_path, rebalance=True)
+    check(v, 1e-5)
+    assert v["final_edges"][0] < 4.6     # the cut started at 60 % of the block and moved left
