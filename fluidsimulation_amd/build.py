@@ -17,6 +17,9 @@ HEADERS = ["sph_device.h", "sph_sort.h", "sph_neighbors.h", "sph_stream.h",
 # non-contracted fp32 (FluidSPHByCPUSystem.cs:72,97,156,219); fused ops are written explicitly.
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math",
+               # packed fp32 (v_pk_*) issues at ~1.5x the cost of a scalar op on gfx950 and needs
+               # register-pair moves: the SLP vectoriser loses 1 % on the force kernel
+               "-fno-slp-vectorize",
                "-Wall", "-Wno-unused-function"]
 
 

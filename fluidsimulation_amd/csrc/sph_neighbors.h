@@ -261,6 +261,7 @@ struct ForceTarget {
     float x, y, z, vx, vy, vz;
     float Pi; // p_i / rho_i^2
     float negInvH, thrF;
+    float tiny; // 1e-30 in a VGPR (a literal operand would slow the instruction down)
 };
 struct ForceAcc {
     float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
@@ -275,14 +276,17 @@ __device__ __forceinline__ void force_pair(const ForceTarget &t, const float4 &c
                                            const float4 &cv, bool notSelf, ForceAcc &a)
 {
     const float dx = t.x - cp.x, dy = t.y - cp.y, dz = t.z - cp.z;
-    float d2;
+    float d2, rinv;
     if (COUNT) {
         d2 = (dx * dx + dy * dy) + dz * dz;
         a.cnt += (notSelf && d2 < t.thrF) ? 1 : 0;
+        rinv = fminf(__builtin_amdgcn_rsqf(d2), 1.0e18f);
     } else {
-        d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        // tiny = 1e-30 keeps rsq finite for the pair (i, i) without a min: r = 1e-15, t = 1 and
+        // both terms are multiplied by d = 0 / v_j - v_i = 0
+        d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, t.tiny)));
+        rinv = __builtin_amdgcn_rsqf(d2);
     }
-    const float rinv = fminf(__builtin_amdgcn_rsqf(d2), 1.0e18f);
     const float r = d2 * rinv;
     const float tt = __builtin_amdgcn_fmed3f(__builtin_fmaf(r, t.negInvH, 1.0f), 0.f, 1.0f);
     const float mt = cp.w * tt;                      // m_j t
@@ -501,6 +505,7 @@ __device__ __forceinline__ bool process_block(TileShared &sh, float4 *recP, floa
                 ps.t.vx = tv.x; ps.t.vy = tv.y; ps.t.vz = tv.z;
                 ps.t.Pi = tv.w; // q_i = p_i / rho_i^2, written by the density kernel
                 ps.t.negInvH = ps.tc.x;
+                ps.t.tiny = 1.0e-30f;
                 ps.t.thrF = COUNT ? tthr[tbase + tloc] : 0.f;
             } else {
                 ps.t.negInvH2 = ps.tc.x;
@@ -596,6 +601,7 @@ __device__ void process_cell_global(TileShared &sh, const NbArgs &A, int lx, int
             ps.t.vx = tv.x; ps.t.vy = tv.y; ps.t.vz = tv.z;
             ps.t.Pi = tv.w;
             ps.t.negInvH = ps.tc.x;
+            ps.t.tiny = 1.0e-30f;
             ps.t.thrF = thr;
         } else {
             ps.t.negInvH2 = ps.tc.x;

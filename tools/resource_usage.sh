@@ -1,7 +1,7 @@
 #!/bin/bash
 # prints per-kernel VGPR / SGPR / scratch / LDS / occupancy of libsphfluid's kernels (gfx950)
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -fvisibility=hidden \
-  -ffp-contract=off -fno-fast-math -Rpass-analysis=kernel-resource-usage \
+  -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Rpass-analysis=kernel-resource-usage \
   "$(dirname "$0")/../fluidsimulation_amd/csrc/sphfluid.hip" -o /tmp/_ru.so 2>&1 | python3 -c '
 import re,sys
 cur=None
