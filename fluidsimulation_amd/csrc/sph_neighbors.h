@@ -92,6 +92,9 @@ struct NbArgs {
     float gx, gy, gz;
     int cap;
     int ablate; // profiling only: 1 = skip the compute phase, 2 = skip the row walk
+    const uint32_t *tileList; // non-empty tiles (k_map_table)
+    uint32_t *tileCtl;        // [0] number of tiles in the list, [queue] next list entry to take
+    int queue;
 };
 
 __device__ __forceinline__ int wrapi(int c, int g) { return c < 0 ? c + g : (c >= g ? c - g : c); }
@@ -639,20 +642,9 @@ __device__ void process_cell_global(TileShared &sh, const NbArgs &A, int lx, int
 
 // ------------------------------------------------------------------------------------------
 template <bool FORCE, bool COUNT>
-__global__ __launch_bounds__(FORCE ? NB_FTHREADS : NB_DTHREADS) void k_neighbors(NbArgs A)
+__device__ __forceinline__ void process_tile(TileShared &sh, float4 *recP, float4 *recV, float *tthr,
+                                             const NbArgs &A, int tile)
 {
-    __shared__ TileShared sh;
-    __shared__ float4 recP[(FORCE ? NB_FCAP : NB_DCAP) + 1]; // x, y, z, m_j (+ the FAR record)
-    __shared__ float4 recV[FORCE ? NB_FCAP + 1 : 1];         // vx, vy, vz, q_j = p_j/rho_j^2
-    __shared__ float tthr[COUNT ? NB_TCAP : 1]; // COUNT variants: exact predicate threshold (h2 / thrF)
-
-    // Tiles are taken in launch order: consecutive workgroups land on different XCDs, which
-    // balances a fluid that fills only part of the grid (one contiguous eighth of the tiles per
-    // XCD measured 5 % slower on the dam break).
-    const int tile = blockIdx.x;
-    if (tile >= A.g.tiles) return;
-    const int2 trange = A.ttable[tile];
-    if (trange.y <= trange.x) return; // no fluid particle in this tile
     tile_lookup(sh, tile, A);
 
     // The largest block whose 27-cell halo fits the LDS tile: the whole tile, then halves
@@ -684,5 +676,27 @@ __global__ __launch_bounds__(FORCE ? NB_FTHREADS : NB_DTHREADS) void k_neighbors
         }
         const int low = cursor & -cursor; // largest aligned block at the new cursor
         size = low >= 16 ? 16 : low >= 8 ? 8 : low >= 4 ? 4 : 1;
+    }
+}
+
+// Persistent workgroups: each takes the next non-empty tile from the list until it is exhausted
+// (every wave leaves through the same uniform test).  The grid is sized to what the chip holds, so
+// no workgroup is launched for the empty part of the table.
+template <bool FORCE, bool COUNT>
+__global__ __launch_bounds__(FORCE ? NB_FTHREADS : NB_DTHREADS) void k_neighbors(NbArgs A)
+{
+    __shared__ TileShared sh;
+    __shared__ float4 recP[(FORCE ? NB_FCAP : NB_DCAP) + 1]; // x, y, z, m_j (+ the FAR record)
+    __shared__ float4 recV[FORCE ? NB_FCAP + 1 : 1];         // vx, vy, vz, q_j = p_j/rho_j^2
+    __shared__ float tthr[COUNT ? NB_TCAP : 1]; // COUNT variants: exact predicate threshold (h2 / thrF)
+    __shared__ uint32_t next;
+    const uint32_t ntiles = (A.ablate & 16) ? 0u : A.tileCtl[0];
+    for (;;) {
+        if (threadIdx.x == 0) next = atomicAdd(&A.tileCtl[A.queue], 1u);
+        __syncthreads();
+        const uint32_t i = next;
+        if (i >= ntiles) break;
+        // the tile's first barrier comes after every thread has read `next`
+        process_tile<FORCE, COUNT>(sh, recP, recV, tthr, A, (int)A.tileList[i]);
     }
 }

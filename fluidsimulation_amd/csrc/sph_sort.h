@@ -197,3 +197,33 @@ __global__ void k_map_table(const uint32_t *__restrict__ skeys, int n, int2 *__r
         if (s == n - 1 || t != kn / SPH_TCELLS) ttable[t].y = s + 1;
     }
 }
+
+// Compacts the non-empty tiles into tileList, tileCtl[0] = their number.  One atomic per block
+// (a single contended counter per tile costs 12 ns each); the order of the list is arbitrary, it
+// only decides which workgroup takes which tile.
+__global__ __launch_bounds__(256) void k_tile_list(const int2 *__restrict__ ttable, int tiles,
+                                                   uint32_t *__restrict__ tileList,
+                                                   uint32_t *__restrict__ tileCtl)
+{
+    __shared__ uint32_t waveCount[4], base;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    bool full = false;
+    if (t < tiles) {
+        const int2 r = ttable[t];
+        full = r.y > r.x;
+    }
+    const unsigned long long m = __ballot(full);
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) waveCount[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = waveCount[0] + waveCount[1] + waveCount[2] + waveCount[3];
+        base = total ? atomicAdd(&tileCtl[0], total) : 0u;
+    }
+    __syncthreads();
+    if (full) {
+        uint32_t off = base + (uint32_t)mbcnt64(m);
+        for (int i = 0; i < w; i++) off += waveCount[i];
+        tileList[off] = (uint32_t)t;
+    }
+}

@@ -95,6 +95,8 @@ struct SphCtx {
     GridDesc grid{};
     bool gridExplicit = false, gridValid = false;
     DevBuf<int2> table, btable, ttable;
+    DevBuf<uint32_t> tileList, tileCtl; // non-empty tiles; [0] their number, [1]/[2] work queues
+    int nbGrid[4] = {0, 0, 0, 0};        // persistent grid of k_neighbors<FORCE,COUNT>
     int fallbackCap = -1; // debug: LDS record cap override for the neighbour kernels
 
     // boundary
@@ -603,7 +605,7 @@ int sph_destroy(SphCtx *c)
     release(c->rho); release(c->prs); release(c->force); release(c->zeros); release(c->dcount); release(c->fcount);
     release(c->hashes); release(c->keysEcs); release(c->cells);
     release(c->io3a); release(c->io3b); release(c->io1); release(c->ioU);
-    release(c->dmats); release(c->table); release(c->btable); release(c->ttable);
+    release(c->dmats); release(c->table); release(c->btable); release(c->ttable); release(c->tileList); release(c->tileCtl);
     release(c->bpos3); release(c->bpar3); release(c->bposmIn); release(c->bposm);
     release(c->bkeysA); release(c->bkeysB); release(c->bvalsA); release(c->bvalsB);
     release(c->boxState); release(c->devBoxes); release(c->bodyImpulse);
@@ -877,14 +879,19 @@ int sph_map_table(SphCtx *c)
     if (!c->haveSort) return fail(c, SPH_E_INVALID, "sph_map_table before sph_radix_sort");
     int rc = ensure(c, c->table, (size_t)c->grid.cells);
     if (!rc) rc = ensure(c, c->ttable, (size_t)c->grid.tiles);
+    if (!rc) rc = ensure(c, c->tileList, (size_t)c->grid.tiles);
+    if (!rc) rc = ensure(c, c->tileCtl, 4, false);
     if (rc) return rc;
     rc = prepare_boundary(c);
     if (rc) return rc;
     StageTimer t(c, SPH_T_TABLE);
     HIPCHK(c, hipMemsetAsync(c->table.p, 0, (size_t)c->grid.cells * sizeof(int2), c->stream));
     HIPCHK(c, hipMemsetAsync(c->ttable.p, 0, (size_t)c->grid.tiles * sizeof(int2), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->tileCtl.p, 0, 4 * sizeof(uint32_t), c->stream));
     k_map_table<<<blocks_for(c->n, 256), 256, 0, c->stream>>>(c->sortedKeys, c->n, c->table.p,
                                                               c->ttable.p);
+    k_tile_list<<<blocks_for(c->grid.tiles, 256), 256, 0, c->stream>>>(
+        c->ttable.p, c->grid.tiles, c->tileList.p, c->tileCtl.p);
     HIPCHK(c, hipGetLastError());
     c->haveTable = true;
     c->ordered = false;
@@ -934,8 +941,30 @@ static NbArgs neighbor_args(SphCtx *c, const SphParams *p, int cap)
     A.gz = p->gravity[2];
     A.cap = c->fallbackCap >= 0 ? std::min(c->fallbackCap, cap) : cap;
     if (const char *e = getenv("SPH_ABLATE")) A.ablate = atoi(e);
+    A.tileList = c->tileList.p;
+    A.tileCtl = c->tileCtl.p;
     return A;
 }
+
+// launches k_neighbors<FORCE,COUNT> as persistent workgroups: as many as the chip holds at once
+extern "C++" {
+template <bool FORCE, bool COUNT> static int launch_neighbors(SphCtx *c, NbArgs &A)
+{
+    constexpr int threads = FORCE ? NB_FTHREADS : NB_DTHREADS;
+    int &grid = c->nbGrid[(FORCE ? 2 : 0) + (COUNT ? 1 : 0)];
+    if (grid == 0) {
+        int perCU = 0;
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_neighbors<FORCE, COUNT>,
+                                                               threads, 0));
+        grid = std::max(1, perCU) * std::max(1, c->prop.multiProcessorCount);
+    }
+    A.queue = FORCE ? 2 : 1;
+    HIPCHK(c, hipMemsetAsync(c->tileCtl.p + A.queue, 0, sizeof(uint32_t), c->stream));
+    k_neighbors<FORCE, COUNT><<<std::min(grid, std::max(c->grid.tiles, 1)), threads, 0, c->stream>>>(A);
+    HIPCHK(c, hipGetLastError());
+    return SPH_OK;
+}
+} // extern "C++"
 
 int sph_compute_density_and_pressure(SphCtx *c, const SphParams *p)
 {
@@ -948,11 +977,11 @@ int sph_compute_density_and_pressure(SphCtx *c, const SphParams *p)
     NbArgs A = neighbor_args(c, p, NB_DCAP);
     if (c->debug & SPH_DEBUG_COUNTS) {
         A.counts = c->dcount.p;
-        k_neighbors<false, true><<<(c->grid.tiles + 7) / 8 * 8, NB_DTHREADS, 0, c->stream>>>(A);
+        rc = launch_neighbors<false, true>(c, A);
     } else {
-        k_neighbors<false, false><<<(c->grid.tiles + 7) / 8 * 8, NB_DTHREADS, 0, c->stream>>>(A);
+        rc = launch_neighbors<false, false>(c, A);
     }
-    HIPCHK(c, hipGetLastError());
+    if (rc) return rc;
     c->haveDensity = true;
     c->rhoInOrder = true;
     return SPH_OK;
@@ -967,11 +996,11 @@ int sph_compute_force(SphCtx *c, const SphParams *p)
     NbArgs A = neighbor_args(c, p, NB_FCAP);
     if (c->debug & SPH_DEBUG_COUNTS) {
         A.counts = c->fcount.p;
-        k_neighbors<true, true><<<(c->grid.tiles + 7) / 8 * 8, NB_FTHREADS, 0, c->stream>>>(A);
+        rc = launch_neighbors<true, true>(c, A);
     } else {
-        k_neighbors<true, false><<<(c->grid.tiles + 7) / 8 * 8, NB_FTHREADS, 0, c->stream>>>(A);
+        rc = launch_neighbors<true, false>(c, A);
     }
-    HIPCHK(c, hipGetLastError());
+    if (rc) return rc;
     c->haveForce = true;
     return SPH_OK;
 }
