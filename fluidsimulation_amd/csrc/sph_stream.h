@@ -195,7 +195,9 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
     const float *__restrict__ rho, const uint32_t *__restrict__ mat,
     const Mat *__restrict__ mats, int n, float dt, const DevBox *__restrict__ boxes, int nboxes,
     float particleRestitution, float *__restrict__ bodyImpulse,
-    const uint32_t *__restrict__ slabFlags /* slab mode: ids with the ghost bit, else nullptr */)
+    const uint32_t *__restrict__ slabFlags /* slab mode: ids with the ghost bit, else nullptr */,
+    uint32_t *__restrict__ nextKeys /* nullable: the next step's cell keys (saves k_keys) */,
+    GridDesc grid)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
@@ -329,6 +331,9 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
     if (live) {
         if (INTEGRATE) posm[i] = make_float4(x[0], x[1], x[2], pv.w);
         velq[i] = make_float4(v[0], v[1], v[2], vv.w);
+        if (INTEGRATE && nextKeys)
+            nextKeys[i] = dense_key(quantize1(x[0], grid.cellSize), quantize1(x[1], grid.cellSize),
+                                    quantize1(x[2], grid.cellSize), grid);
     }
 }
 

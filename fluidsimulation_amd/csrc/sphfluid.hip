@@ -1005,7 +1005,8 @@ int sph_compute_force(SphCtx *c, const SphParams *p)
     return SPH_OK;
 }
 
-static int launch_apply_integrate(SphCtx *c, const SphParams *p, bool apply, bool integrate)
+static int launch_apply_integrate(SphCtx *c, const SphParams *p, bool apply, bool integrate,
+                                  bool nextKeys = false)
 {
     const int N = c->n, cur = c->cur;
     const int nb = blocks_for(N, 256);
@@ -1013,7 +1014,7 @@ static int launch_apply_integrate(SphCtx *c, const SphParams *p, bool apply, boo
     k_apply_integrate<A, I><<<nb, 256, 0, c->stream>>>(                                          \
         c->posm[cur].p, c->velq[cur].p, c->force.p, c->rho.p, c->mat[cur].p, c->dmats.p, N,      \
         p->dt, c->devBoxes.p, c->nboxes, p->particleRestitution, c->bodyImpulse.p,               \
-        c->slab ? c->oid[cur].p : nullptr)
+        c->slab ? c->oid[cur].p : nullptr, nextKeys ? c->keysA.p : nullptr, c->grid)
     if (apply && integrate) LAUNCH_AI(true, true);
     else if (apply) LAUNCH_AI(true, false);
     else LAUNCH_AI(false, true);
@@ -1066,16 +1067,27 @@ int sph_step_resident(SphCtx *c, const SphParams *p, int32_t nsteps)
     if (c->slab && c->anyDynamicBox)
         return fail(c, SPH_E_INVALID, "slab mode with dynamic boxes: use sph_slab_step_particles, "
                                       "sum the impulses over ranks, sph_slab_step_bodies");
+    // Inside the loop the integrate kernel also writes the next step's cell keys (it holds the
+    // new position in registers), which saves the k_keys pass; not with the parity outputs of
+    // SPH_DEBUG_HASHES and not in slab mode (dead ghosts carry their own key).
+    const bool fuse = !c->slab && !(c->debug & SPH_DEBUG_HASHES);
+    bool keysReady = false;
     for (int s = 0; s < nsteps; s++) {
-        if ((rc = sph_hash_position(c, p))) return rc;
+        if (keysReady) {
+            if ((rc = sync_params(c, p))) return rc;
+            c->haveKeys = true;
+        } else if ((rc = sph_hash_position(c, p))) {
+            return rc;
+        }
         if ((rc = sph_radix_sort(c))) return rc;
         if ((rc = sph_map_table(c))) return rc;
         if ((rc = sph_reorder(c))) return rc;
         if ((rc = sph_compute_density_and_pressure(c, p))) return rc;
         if ((rc = sph_compute_force(c, p))) return rc;
+        keysReady = fuse && s + 1 < nsteps;
         {
             StageTimer t(c, SPH_T_INTEGRATE);
-            if ((rc = launch_apply_integrate(c, p, true, true))) return rc;
+            if ((rc = launch_apply_integrate(c, p, true, true, keysReady))) return rc;
         }
         c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
         c->haveDensity = c->haveForce = false;
