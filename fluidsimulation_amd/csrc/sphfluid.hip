@@ -55,6 +55,8 @@ struct MatKeyHash {
 
 } // namespace
 
+#define SPH_QUEUE_SLOTS 64 // tileCtl: [0] number of listed tiles, [1..63] work-queue counters
+
 struct SphCtx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -97,6 +99,7 @@ struct SphCtx {
     DevBuf<int2> table, btable, ttable;
     DevBuf<uint32_t> tileList, tileCtl; // non-empty tiles; [0] their number, [1]/[2] work queues
     int nbGrid[4] = {0, 0, 0, 0};        // persistent grid of k_neighbors<FORCE,COUNT>
+    int queueNext = 1;                   // next unused work-queue slot of tileCtl
     int fallbackCap = -1; // debug: LDS record cap override for the neighbour kernels
 
     // boundary
@@ -880,14 +883,15 @@ int sph_map_table(SphCtx *c)
     int rc = ensure(c, c->table, (size_t)c->grid.cells);
     if (!rc) rc = ensure(c, c->ttable, (size_t)c->grid.tiles);
     if (!rc) rc = ensure(c, c->tileList, (size_t)c->grid.tiles);
-    if (!rc) rc = ensure(c, c->tileCtl, 4, false);
+    if (!rc) rc = ensure(c, c->tileCtl, SPH_QUEUE_SLOTS, false);
     if (rc) return rc;
     rc = prepare_boundary(c);
     if (rc) return rc;
     StageTimer t(c, SPH_T_TABLE);
     HIPCHK(c, hipMemsetAsync(c->table.p, 0, (size_t)c->grid.cells * sizeof(int2), c->stream));
     HIPCHK(c, hipMemsetAsync(c->ttable.p, 0, (size_t)c->grid.tiles * sizeof(int2), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->tileCtl.p, 0, 4 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->tileCtl.p, 0, SPH_QUEUE_SLOTS * sizeof(uint32_t), c->stream));
+    c->queueNext = 1;
     k_map_table<<<blocks_for(c->n, 256), 256, 0, c->stream>>>(c->sortedKeys, c->n, c->table.p,
                                                               c->ttable.p);
     k_tile_list<<<blocks_for(c->grid.tiles, 256), 256, 0, c->stream>>>(
@@ -958,8 +962,14 @@ template <bool FORCE, bool COUNT> static int launch_neighbors(SphCtx *c, NbArgs 
                                                                threads, 0));
         grid = std::max(1, perCU) * std::max(1, c->prop.multiProcessorCount);
     }
-    A.queue = FORCE ? 2 : 1;
-    HIPCHK(c, hipMemsetAsync(c->tileCtl.p + A.queue, 0, sizeof(uint32_t), c->stream));
+    // every launch takes a fresh (zero) queue slot; they are all cleared with the tile table, so
+    // there is no per-launch memset (a 4-byte hipMemsetAsync costs 20 us on the device)
+    if (c->queueNext >= SPH_QUEUE_SLOTS) {
+        HIPCHK(c, hipMemsetAsync(c->tileCtl.p + 1, 0, (SPH_QUEUE_SLOTS - 1) * sizeof(uint32_t),
+                                 c->stream));
+        c->queueNext = 1;
+    }
+    A.queue = c->queueNext++;
     k_neighbors<FORCE, COUNT><<<std::min(grid, std::max(c->grid.tiles, 1)), threads, 0, c->stream>>>(A);
     HIPCHK(c, hipGetLastError());
     return SPH_OK;
