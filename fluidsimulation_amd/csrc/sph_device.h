@@ -40,7 +40,9 @@ struct Mat {
     float h, h2, thrF, poly6;      // poly6 = mass*315/(64*PI*h^9)
     float restDensity, gasConstant, viscosity, mass;
     float invMass, radius, spiky;  // spiky = 45/(PI*h^6)
-    float pad;
+    float negInvH;                 // -1/h, -1/h2, poly6*h2^3: per-target constants of the
+    float negInvH2, poly6h6;       // neighbour kernels, divided once on the host
+    float pad[2];
 };
 
 // Box collider in the form the integrate kernel reads (row-major rotation, world = R*local)

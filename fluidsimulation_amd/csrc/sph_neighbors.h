@@ -327,7 +327,8 @@ template <bool COUNT> struct Pass<false, COUNT> {
             const float pressure = fmaxf(tc.z * (density - tc.w), 0.f);
             A.rho[ti] = density;
             A.prs[ti] = pressure;
-            A.velq[ti].w = pressure / (density * density);
+            // q = p / rho^2 through v_rcp: 1 ulp, it only enters the force sums
+            A.velq[ti].w = pressure * __builtin_amdgcn_rcpf(density * density);
             if (COUNT) A.counts[ti] = c2;
         }
     }
@@ -365,11 +366,11 @@ __device__ __forceinline__ void target_constants(const NbArgs &A, int gi, float4
     if (FORCE) {
         const float d = A.rhoIn[gi];
         // -1/h, rho_i*45/(pi h^6)*h^2, mu_i/rho_i*45/(pi h^6)*h, rho_i
-        tc = make_float4(-1.0f / m.h, d * m.spiky * (m.h * m.h), m.viscosity / d * m.spiky * m.h, d);
+        tc = make_float4(m.negInvH, d * m.spiky * (m.h * m.h), m.viscosity / d * m.spiky * m.h, d);
         thr = m.thrF;
     } else {
-        const float scale = COUNT ? m.poly6 : m.poly6 * (m.h2 * m.h2 * m.h2);
-        tc = make_float4(-1.0f / m.h2, scale, m.gasConstant, m.restDensity);
+        const float scale = COUNT ? m.poly6 : m.poly6h6;
+        tc = make_float4(m.negInvH2, scale, m.gasConstant, m.restDensity);
         thr = m.h2;
     }
 }

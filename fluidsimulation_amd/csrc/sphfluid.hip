@@ -254,6 +254,9 @@ Mat make_mat(const MatKey &k, float rate)
     for (int i = 0; i < 8 && t > 0.f && sqrtf(nextafterf(t, 0.f)) >= m.h; i++) t = nextafterf(t, 0.f);
     for (int i = 0; i < 8 && sqrtf(t) < m.h; i++) t = nextafterf(t, INFINITY);
     m.thrF = t;
+    m.negInvH = -1.0f / m.h;
+    m.negInvH2 = -1.0f / m.h2;
+    m.poly6h6 = m.poly6 * (m.h2 * m.h2 * m.h2);
     return m;
 }
 
