@@ -53,10 +53,10 @@
 #define NB_FG 4 // same, force
 #endif
 #ifndef NB_DCAP
-#define NB_DCAP 1728 // LDS records per block, density kernel (27 KB): four workgroups per CU
+#define NB_DCAP 1600 // LDS records per block, density kernel (25 KB): four workgroups per CU
 #endif
 #ifndef NB_FCAP
-#define NB_FCAP 1280 // LDS records per block, force kernel (2 x 20 KB): three workgroups per CU
+#define NB_FCAP 1216 // LDS records per block, force kernel (2 x 19 KB): three workgroups per CU
 #endif
 #define NB_TCAP 512  // targets per block whose constants are cached in LDS
 
@@ -71,6 +71,8 @@ struct TileShared {
     int2 cellf[SPH_TCELLS]; // per block cell: halo index in the tile, halo index in the block
     int4 cdesc[SPH_TCELLS];    // per cell of the block: targets, global start, LDS start, ordinal
     int scan[2 * NB_MAXWAVES];
+    unsigned char rcell[NB_DCAP > NB_FCAP ? NB_DCAP : NB_FCAP]; // record -> halo cell of the block
+    unsigned char tcell[NB_TCAP];                               // target -> cell of the block
     float4 tconst[NB_TCAP];   // per-target constants of the block's own particles
 };
 
@@ -159,18 +161,6 @@ template <int N> __device__ __forceinline__ void fold_slices(float (&v)[N], int 
             c += in ? xc : 0;
         }
     }
-}
-
-// last index i in [0, n) with a[i] <= q (a non-decreasing, a[0] <= q)
-__device__ __forceinline__ int bisect_le(const int *a, int n, int q)
-{
-    int lo = 0, hi = n - 1;
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (a[mid] <= q) lo = mid; else hi = mid - 1;
-    }
-    return lo;
 }
 
 // exclusive scan of two values per thread over the 256-thread block
@@ -405,9 +395,19 @@ __device__ __forceinline__ bool process_block(TileShared &sh, float4 *recP, floa
     block_scan2(sh, cnt, tcnt, e1, e2, total, ttotal);
     if (total > cap || ttotal > NB_TCAP) return false;
     if (ttotal == 0) return true;
-    if (tid < nh) sh.spref[tid] = e1;
+    // besides the prefix sums, every record and every target gets the index of its cell (a byte
+    // each): the staging loops below then look it up instead of bisecting the prefix sums
+    if (tid < nh) {
+        sh.spref[tid] = e1;
+#pragma nounroll
+        for (int k = e1; k < e1 + cnt; k++) sh.rcell[k] = (unsigned char)tid;
+    }
     if (tid == nh) sh.spref[nh] = total;
-    if (tid < ncells) sh.tpref[tid] = e2;
+    if (tid < ncells) {
+        sh.tpref[tid] = e2;
+#pragma nounroll
+        for (int k = e2; k < e2 + tcnt; k++) sh.tcell[k] = (unsigned char)tid;
+    }
     if (tid == ncells) sh.tpref[ncells] = ttotal;
     __syncthreads();
 
@@ -416,7 +416,7 @@ __device__ __forceinline__ bool process_block(TileShared &sh, float4 *recP, floa
         const int qw = q0 + w * 64; // first record of this wave-instruction (wave-uniform)
         const int q = qw + lane;
         if (q < total) {
-            const int hcell = bisect_le(sh.spref, nh, q);
+            const int hcell = sh.rcell[q];
             const int f = sh.hmap[hcell];
             const int k = q - sh.spref[hcell], fc = sh.fc[f];
             const float4 *gp, *gv;
@@ -432,7 +432,7 @@ __device__ __forceinline__ bool process_block(TileShared &sh, float4 *recP, floa
         }
     }
     for (int i = tid; i < ttotal; i += NB_THREADS) {
-        const int c = bisect_le(sh.tpref, ncells, i);
+        const int c = sh.tcell[i];
         const int f = sh.cellf[c].x;
         float4 tc;
         float thr;
@@ -684,7 +684,9 @@ __device__ __forceinline__ void process_tile(TileShared &sh, float4 *recP, float
 // (every wave leaves through the same uniform test).  The grid is sized to what the chip holds, so
 // no workgroup is launched for the empty part of the table.
 template <bool FORCE, bool COUNT>
-__global__ __launch_bounds__(FORCE ? NB_FTHREADS : NB_DTHREADS) void k_neighbors(NbArgs A)
+// second launch bound = waves per SIMD the register allocation must allow (what the LDS allows)
+__global__ __launch_bounds__(FORCE ? NB_FTHREADS : NB_DTHREADS, (FORCE ? 3 : 4) - (COUNT ? 1 : 0))
+void k_neighbors(NbArgs A)
 {
     __shared__ TileShared sh;
     __shared__ float4 recP[(FORCE ? NB_FCAP : NB_DCAP) + 1]; // x, y, z, m_j (+ the FAR record)
