@@ -47,10 +47,10 @@
 #endif
 #define NB_MAXWAVES 8
 #ifndef NB_DG
-#define NB_DG 4 // candidate records in flight per lane, density
+#define NB_DG 3 // candidate records in flight per lane, density
 #endif
 #ifndef NB_FG
-#define NB_FG 4 // same, force
+#define NB_FG 3 // same, force
 #endif
 #ifndef NB_DCAP
 #define NB_DCAP 1600 // LDS records per block, density kernel (25 KB): four workgroups per CU
