@@ -189,7 +189,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, a.config, n) if world == 1 else None,
-                         "limiter": "fp32 VALU issue (SQ_INSTS_VALU x 4 cycles = 88-99 % of the "
+                         "limiter": "fp32 VALU issue (SQ_INSTS_VALU x 4 cycles = 98-99 % of the "
                                     "kernel's SIMD cycles, profiles/), not HBM",
                          "alg_bytes_per_particle": alg[dom],
                          "avg_launch_ms": stage_ms[dom]},

@@ -100,6 +100,7 @@ struct SphCtx {
     DevBuf<uint32_t> tileList, tileCtl; // non-empty tiles; [0] their number, [1]/[2] work queues
     int nbGrid[4] = {0, 0, 0, 0};        // persistent grid of k_neighbors<FORCE,COUNT>
     int queueNext = 1;                   // next unused work-queue slot of tileCtl
+    int ablate = 0;                      // profiling switch (env SPH_ABLATE, read at sph_create)
     int fallbackCap = -1; // debug: LDS record cap override for the neighbour kernels
 
     // boundary
@@ -595,6 +596,7 @@ int sph_create(const SphConfig *cfg, SphCtx **out)
     }
     if (cfg && cfg->maxCells > 0) c->maxCells = std::max(cfg->maxCells, 64);
     c->timing = cfg && cfg->enableTimings;
+    if (const char *e = getenv("SPH_ABLATE")) c->ablate = atoi(e); // tools/ablate.sh only
     *out = c;
     return SPH_OK;
 }
@@ -947,7 +949,7 @@ static NbArgs neighbor_args(SphCtx *c, const SphParams *p, int cap)
     A.gy = p->gravity[1];
     A.gz = p->gravity[2];
     A.cap = c->fallbackCap >= 0 ? std::min(c->fallbackCap, cap) : cap;
-    if (const char *e = getenv("SPH_ABLATE")) A.ablate = atoi(e);
+    A.ablate = c->ablate;
     A.tileList = c->tileList.p;
     A.tileCtl = c->tileCtl.p;
     return A;
