@@ -246,3 +246,33 @@ def test_full_size_properties(ctx, oracle, config):
     forces, _ = oracle.force(sc.pos[idx], sc.inv_mass[idx], sc.vel[idx], sc.params[idx],
                              sc.bpos[bh], sc.bparams[bh], gd[idx], okp, 1.0)
     assert_close(gf[idx][core], forces[core], rtol=5e-5, what="force slab")
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_graded_density_exercises_every_block_shape(ctx, oracle, seed):
+    """a tank whose particle density rises from a few to ~80 per cell along x, random velocities and
+    two materials: tiles fall through every block shape (whole tile, 4x4x1, 4x2x1, 2x2x1, single
+    cell, global memory); counts bit-exact and values to tolerance in both kernel variants"""
+    rng = np.random.default_rng(seed)
+    n = 9000
+    u = rng.random(n)
+    x = 12.0 * u ** 0.4                        # density ~ x^1.5
+    pos = np.stack([x, rng.uniform(0.0, 6.0, n), rng.uniform(0.0, 4.0, n)], axis=1).astype(np.float32)
+    sc = scene.dam_break(8, 12, 8)             # boundary layers and boxes of a 12 x 6 x 4 tank
+    sc.pos = pos
+    sc.vel = rng.normal(0.0, 2.0, (n, 3)).astype(np.float32)
+    sc.params = np.tile(sc.params[:1], (n, 1))
+    sc.params[rng.random(n) < 0.3, 1] = 800.0
+    sc.inv_mass = np.where(rng.random(n) < 0.5, 1.0 / 125.0, 1.0 / 100.0).astype(np.float32)
+    dens, pres, cnt = oracle.density_pressure(sc.pos, sc.inv_mass, sc.params, sc.bpos, 1.0)
+    forces, fcnt = oracle.force(sc.pos, sc.inv_mass, sc.vel, sc.params, sc.bpos, sc.bparams,
+                                dens, pres, 1.0)
+    assert cnt.max() > 150 and cnt.min() < 40
+    for debug in (native.SPH_DEBUG_COUNTS, 0):
+        p = load_scene(ctx, sc, debug=debug)
+        run_to_force(ctx, p)
+        if debug:
+            np.testing.assert_array_equal(ctx.read(native.SPH_BUF_DENSITY_COUNTS), cnt)
+            np.testing.assert_array_equal(ctx.read(native.SPH_BUF_FORCE_COUNTS), fcnt)
+        assert_close(ctx.read(native.SPH_BUF_DENSITIES), dens, what="density")
+        assert_close(ctx.read(native.SPH_BUF_FORCES), forces, rtol=5e-5, what="force")
