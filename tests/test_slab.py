@@ -77,6 +77,12 @@ def test_slab_exchange_on_the_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_slab_middle_rank_on_the_gpu(tmp_path):
+    """three ranks on device 0: the middle one packs, sends and imports on both faces"""
+    check(run_ranks("hip", 3, 4, tmp_path), 1e-5)
+
+
+@pytest.mark.gpu
 def test_slab_rigid_body_on_the_gpu(tmp_path):
     v = run_ranks("hip", 2, 4, tmp_path, bodies=True)
     check(v, 1e-5)
