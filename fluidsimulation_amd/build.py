@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsphfluid.so")
 SOURCES = ["sphfluid.hip"]
-HEADERS = ["sph_device.h", "sph_sort.h", "sph_neighbors.h", "sph_stream.h",
-           os.path.join("..", "..", "include", "sphfluid.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + \
+    [os.path.join("..", "..", "include", "sphfluid.h")]
 
 # -ffp-contract=off: the neighbour predicates must round exactly like the reference's
 # non-contracted fp32 (FluidSPHByCPUSystem.cs:72,97,156,219); fused ops are written explicitly.

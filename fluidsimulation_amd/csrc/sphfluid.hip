@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -56,6 +57,23 @@ struct MatKeyHash {
 } // namespace
 
 #define SPH_QUEUE_SLOTS 64 // tileCtl: [0] number of listed tiles, [1..63] work-queue counters
+
+// ---- scratch of sph_sort_pairs_noalloc ------------------------------------------------------
+// The one entry point that allocates nothing keeps its scratch (one ping-pong (key, value) buffer,
+// the per-tile digit histograms and the digit totals of the radix sort) in this file-scope device
+// array.  Every GPU the library runs on holds its own copy until the process ends; `scratch` is
+// only a host-side stand-in for it, the device address is taken once per device in sph_create
+// (hipGetSymbolAddress with that device current) and kept in g_scratchPtr.
+struct SortScratch {
+    uint32_t keys[SPH_SORT_NOALLOC_MAX];
+    uint32_t vals[SPH_SORT_NOALLOC_MAX];
+    uint32_t hist[256 * ((SPH_SORT_NOALLOC_MAX + RS_TILE - 1) / RS_TILE)];
+    uint32_t rowTotal[256];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(SortScratch)];
+#define SPH_MAX_DEVICES 64
+static SortScratch *g_scratchPtr[SPH_MAX_DEVICES]; // per device; written under g_scratchLock
+static std::mutex g_scratchLock;
 
 struct SphCtx {
     int device = 0;
@@ -593,6 +611,20 @@ int sph_create(const SphConfig *cfg, SphCtx **out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail(nullptr, SPH_E_DEVICE, "hipStreamCreate failed");
+    }
+    if (dev < SPH_MAX_DEVICES) { // this device's copy of `scratch` (device `dev` is current)
+        std::lock_guard<std::mutex> lk(g_scratchLock);
+        if (!g_scratchPtr[dev]) {
+            void *ptr = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !ptr) {
+                (void)hipStreamDestroy(c->stream);
+                delete c;
+                return fail(nullptr, SPH_E_DEVICE, "hipGetSymbolAddress(scratch): %s",
+                            hipGetErrorString(e));
+            }
+            g_scratchPtr[dev] = (SortScratch *)ptr;
+        }
     }
     if (cfg && cfg->maxCells > 0) c->maxCells = std::max(cfg->maxCells, 64);
     c->timing = cfg && cfg->enableTimings;
@@ -1297,6 +1329,45 @@ int sph_sort_pairs(SphCtx *c, const uint32_t *keys, int32_t n, int32_t bits, uin
     }
     release(ka); release(kb); release(va); release(vb);
     return rc;
+}
+
+// Stable LSD radix sort of device keys into (keys_out, perm_out) with every intermediate in the
+// static scratch: pass p writes to the caller's outputs or to the scratch pair, alternating so
+// that the last pass lands in the outputs.  No hipMalloc / hipFree here or below.
+int sph_sort_pairs_noalloc(SphCtx *c, const uint32_t *keys_dev, int32_t n, int32_t bits,
+                           uint32_t *perm_out_dev, uint32_t *keys_out_dev)
+{
+    if (!c) return SPH_E_INVALID;
+    if (n < 0 || bits < 1 || bits > 32 || (n > 0 && (!keys_dev || !perm_out_dev || !keys_out_dev)))
+        return fail(c, SPH_E_INVALID, "bad sort arguments");
+    if (n > SPH_SORT_NOALLOC_MAX)
+        return fail(c, SPH_E_TOOLARGE, "sph_sort_pairs_noalloc: n = %d beyond the static scratch "
+                                       "(at most %d keys)", n, SPH_SORT_NOALLOC_MAX);
+    if (n == 0) return SPH_OK;
+    if (keys_dev == keys_out_dev || (const void *)keys_dev == (const void *)perm_out_dev ||
+        keys_out_dev == perm_out_dev)
+        return fail(c, SPH_E_INVALID, "sph_sort_pairs_noalloc: buffers must not alias");
+    if (c->device >= SPH_MAX_DEVICES || !g_scratchPtr[c->device])
+        return fail(c, SPH_E_DEVICE, "no static scratch on device %d", c->device);
+    HIPCHK(c, hipSetDevice(c->device));
+    SortScratch *sc = g_scratchPtr[c->device]; // device address, never the symbol's name
+    const int nblocks = blocks_for(n, RS_TILE);
+    const int passes = (bits + 7) / 8;
+    uint32_t *dk[2] = {keys_out_dev, sc->keys}, *dv[2] = {perm_out_dev, sc->vals};
+    const uint32_t *kin = keys_dev, *vin = nullptr; // values of pass 0 are the indices
+    for (int p = 0; p < passes; p++) {
+        const int d = (p + passes - 1) & 1; // the last pass has d == 0: the caller's outputs
+        // hist and rowTotal are written in full by k_radix_hist / k_radix_scan before they are
+        // read, so nothing of the previous call's contents has to be cleared
+        k_radix_hist<<<nblocks, RS_THREADS, 0, c->stream>>>(kin, n, 8 * p, sc->hist, nblocks);
+        k_radix_scan<<<256, RS_THREADS, 0, c->stream>>>(sc->hist, sc->rowTotal, nblocks);
+        k_radix_scatter<<<nblocks, RS_THREADS, 0, c->stream>>>(kin, vin, dk[d], dv[d], n, 8 * p,
+                                                                sc->hist, sc->rowTotal, nblocks);
+        kin = dk[d];
+        vin = dv[d];
+    }
+    HIPCHK(c, hipGetLastError());
+    return SPH_OK;
 }
 
 int sph_get_timings(SphCtx *c, SphTimings *out)

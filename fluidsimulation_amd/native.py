@@ -26,6 +26,7 @@ STAGE_NAMES = ["keys", "sort", "table", "reorder", "density", "force", "integrat
  SPH_BUF_BOUNDARY_TABLE) = range(15)
 
 SPH_DEBUG_HASHES, SPH_DEBUG_COUNTS, SPH_DEBUG_NO_LDS_TILE = 1, 2, 4
+SPH_SORT_NOALLOC_MAX = 1 << 20
 
 # every symbol include/sphfluid.h declares (tests check that the library exports them all)
 EXPORTS = [
@@ -36,7 +37,7 @@ EXPORTS = [
     "sph_hash_position", "sph_radix_sort", "sph_map_table", "sph_reorder",
     "sph_compute_density_and_pressure", "sph_compute_force", "sph_apply_force", "sph_integrate",
     "sph_step_resident", "sph_step", "sph_step_compat", "sph_read", "sph_find_bounds",
-    "sph_sort_pairs", "sph_get_timings", "sph_reset_timings",
+    "sph_sort_pairs", "sph_sort_pairs_noalloc", "sph_get_timings", "sph_reset_timings",
     "sph_slab_upload", "sph_slab_pack", "sph_slab_import", "sph_slab_counts", "sph_slab_download",
     "sph_slab_step_particles", "sph_slab_get_impulses", "sph_slab_step_bodies",
 ]
@@ -117,6 +118,7 @@ def load():
     lib.sph_read.argtypes = [vp, i32, vp, C.c_size_t]
     lib.sph_find_bounds.argtypes = [vp, f32, vp, vp]
     lib.sph_sort_pairs.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.sph_sort_pairs_noalloc.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.sph_get_timings.argtypes = [vp, C.POINTER(SphTimings)]
     lib.sph_slab_upload.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, f32, i32]
     lib.sph_slab_pack.argtypes = [vp, f32, f32, f32, vp, vp, i32, C.POINTER(i32 * 4)]
@@ -349,6 +351,11 @@ class Context:
         self._chk(self.lib.sph_sort_pairs(self.h, _ptr(keys), len(keys), key_bits, _ptr(perm),
                                           _ptr(skeys)))
         return perm, skeys
+
+    def sort_pairs_noalloc(self, keys_ptr, n, key_bits, perm_out_ptr, keys_out_ptr):
+        """device pointers (plain integers); asynchronous on the context's stream"""
+        self._chk(self.lib.sph_sort_pairs_noalloc(self.h, keys_ptr, n, key_bits, perm_out_ptr,
+                                                  keys_out_ptr))
 
     def timings(self):
         t = SphTimings()

@@ -230,6 +230,18 @@ SPH_API int sph_find_bounds(SphCtx *ctx, float gridSize, float mn_out[3], float 
 /* the radix sort on its own: stable ascending sort of ids 0..n-1 by the low key_bits of keys */
 SPH_API int sph_sort_pairs(SphCtx *ctx, const uint32_t *keys, int32_t n, int32_t key_bits,
                            uint32_t *perm_out, uint32_t *sorted_keys_out);
+/* No counterpart in the reference.  For callers that cannot allocate -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc: sph_sort_pairs with DEVICE
+ * pointers for keys and outputs, every intermediate (one ping-pong (key, value) buffer, the
+ * digit histograms) in a file-scope device array of the library, so the call makes no hipMalloc /
+ * hipFree.  n <= SPH_SORT_NOALLOC_MAX, else SPH_E_TOOLARGE.  keys_dev is not written; the three
+ * buffers must not alias.  Asynchronous on the context's stream (sph_synchronize to wait).  All
+ * calls on one GPU share that GPU's array (about 8.3 MB, held until the process ends): calls that
+ * overlap on one GPU -- two contexts, two threads -- race. */
+#define SPH_SORT_NOALLOC_MAX (1 << 20)
+SPH_API int sph_sort_pairs_noalloc(SphCtx *ctx, const uint32_t *keys_dev, int32_t n,
+                                   int32_t key_bits, uint32_t *perm_out_dev,
+                                   uint32_t *sorted_keys_out_dev);
 SPH_API int sph_get_timings(SphCtx *ctx, SphTimings *out); /* synchronises */
 SPH_API int sph_reset_timings(SphCtx *ctx);
 

@@ -8,13 +8,15 @@
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 #define ITERS 16384
-template <int MODE> __global__ __launch_bounds__(256) void k(float *out, float s, unsigned long long *clk)
+template <int MODE> __global__ __launch_bounds__(256) void k(float *out, float s, unsigned long long *clk,
+                                                           unsigned long long *rclk)
 {
     float a[8];
     float2v p[8];
     for (int i = 0; i < 8; i++) { a[i] = threadIdx.x * 0.001f + i; p[i] = float2v{a[i], a[i] + 1.f}; }
     float2v s2 = {s, s * 0.5f};
     int li = threadIdx.x & 7;
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < ITERS; it++) {
 #pragma unroll
@@ -46,34 +48,50 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *out, float s
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float r = 0;
     for (int i = 0; i < 8; i++) r += a[i] + p[i].x + p[i].y;
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
-    if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
+    if (threadIdx.x == 0) { clk[blockIdx.x] = t1 - t0; rclk[blockIdx.x] = r1 - r0; }
 }
 
 template <int MODE> void run(const char *name, int wavesPerSimd, float *d, unsigned long long *clk)
 {
     int blocks = 256 * wavesPerSimd; // 256 threads = 4 waves = one per SIMD
-    k<MODE><<<blocks, 256>>>(d, 1.0001f, clk);
+    unsigned long long *rclk = clk + 256 * 8;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k<MODE><<<blocks, 256>>>(d, 1.0001f, clk, rclk);
     (void)hipDeviceSynchronize();
-    k<MODE><<<blocks, 256>>>(d, 1.0001f, clk);
+    (void)hipEventRecord(e0, 0);
+    k<MODE><<<blocks, 256>>>(d, 1.0001f, clk, rclk);
+    (void)hipEventRecord(e1, 0);
     (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> h(blocks);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(blocks), hr(blocks);
     (void)hipMemcpy(h.data(), clk, blocks * 8, hipMemcpyDeviceToHost);
-    double avg = 0;
+    (void)hipMemcpy(hr.data(), rclk, blocks * 8, hipMemcpyDeviceToHost);
+    double avg = 0, ravg = 0;
     for (auto v : h) avg += (double)v;
-    avg /= blocks;
-    // each wave ran ITERS*8 instructions in avg cycles while sharing its SIMD with wavesPerSimd waves
-    printf("%-22s w/SIMD=%d  %.2f cycles per wave-instruction per SIMD\n", name, wavesPerSimd,
-           avg / (ITERS * 8.0) / wavesPerSimd);
+    for (auto v : hr) ravg += (double)v;
+    avg /= blocks; ravg /= blocks;
+    // (a) each wave ran ITERS*8 instructions in avg shader cycles while sharing its SIMD with
+    //     wavesPerSimd waves (if the blocks are spread evenly, w per CU);
+    // (b) the same from the launch's wall time (HIP events): all 1024 SIMDs of the chip issued
+    //     blocks*4*ITERS*8 wave-instructions in ms at the in-kernel clock s_memtime/s_memrealtime
+    const double ghz = avg / ravg * 0.1;
+    const double wallCyc = ms * 1e-3 * ghz * 1e9 * 1024.0 / ((double)blocks * 4 * ITERS * 8.0);
+    printf("%-22s w/SIMD=%d  in-wave %.2f  wall %.2f cycles per wave-instruction per SIMD  (clock %.2f GHz, %.3f ms)\n",
+           name, wavesPerSimd, avg / (ITERS * 8.0) / wavesPerSimd, wallCyc, ghz, ms);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
 
 int main()
 {
     float *d; (void)hipMalloc(&d, 256 * 8 * 256 * 4 * 4);
-    unsigned long long *clk; (void)hipMalloc(&clk, 256 * 8 * 8);
-    for (int w : {2, 4}) {
+    unsigned long long *clk; (void)hipMalloc(&clk, 2 * 256 * 8 * 8);
+    for (int w : {1, 2, 4, 8}) {
         run<0>("v_fma_f32", w, d, clk);
         run<1>("v_mul_f32", w, d, clk);
         run<8>("v_add_f32", w, d, clk);
