@@ -69,9 +69,35 @@ def measured_traffic(kernel, config, n):
         return None
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes
+    (torch.distributed.run, one per GPU) before anything in this process has touched the GPU,
+    relay their output (rank 0 prints the JSON line) and exit with their status."""
+    import socket
+    import subprocess
+    import torch
+    comm = os.environ.get("SPH_BENCH_COMM", "nccl")
+    ngpu = torch.cuda.device_count()      # counting devices does not initialise the GPU
+    if comm == "nccl" and ngpu < a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but {ngpu} GPU(s) visible; RCCL needs one GPU per "
+                 f"rank (SPH_BENCH_COMM=gloo rehearses the exchange on fewer GPUs than ranks)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -115,10 +141,13 @@ def main():
         ctx = native.Context(device=local, timings=True)
         ctx.set_boundary(sc.bpos, sc.bparams)
         ctx.set_colliders(sc.boxes)
-        face = ny * nz * 4            # lattice sites within the 2 h halo of one face
+        face = ny * nz * 4            # lattice sites within the 2 h halo of one face at t = 0
+        # the fluid piles up against the far wall while it runs: room for 3x the rest-state halo
+        # population in every exchange buffer, and for two generations of ghosts from both sides
+        buf = 12 * face
         ctx.slab_upload(sc.pos, sc.vel, index, ids, table, sc.grid_size,
-                        capacity=sc.n + 16 * face)
-        be = slab.HipSlabBackend(ctx, p, f"cuda:{local}", buffer_records=4 * face)
+                        capacity=sc.n + 4 * buf)
+        be = slab.HipSlabBackend(ctx, p, f"cuda:{local}", buffer_records=buf)
         sim = slab.SlabSimulation(be, edges, halo=2.0 * sc.grid_size)
         n_local = sc.n
         parallelism = (f"x-slab decomposition over {world} ranks, ghosts within 2h + ownership "
@@ -185,7 +214,8 @@ def main():
             "unit": "particle-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "particles_per_gpu": n, "parallelism": parallelism},
+            "config": {"workload": workload, "particles_per_gpu": n, "parallelism": parallelism,
+                       "comm_backend": (dist.get_backend() if dist is not None else "none")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, a.config, n) if world == 1 else None,

@@ -14,7 +14,10 @@
 // 32-byte exchange record = two float4: (x, y, z, bits(material)), (vx, vy, vz, bits(id | flags))
 
 // appends to side[0] (x < lo + halo) / side[1] (x >= hi - halo); counters: records left, right,
-// transfers left, right.  One atomic per wave and side.
+// transfers left, right.  One atomic per wave and side.  COUNT_ONLY: the counters alone, nothing
+// is written and no record changes state (sph_slab_pack sizes the call with it, so that a buffer
+// that is too small is reported before anything has happened).
+template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256) void k_slab_pack(
     const float4 *__restrict__ posm, const float4 *__restrict__ velq,
     const uint32_t *__restrict__ mat, uint32_t *__restrict__ oid, int n, float lo, float hi,
@@ -28,14 +31,14 @@ __global__ __launch_bounds__(256) void k_slab_pack(
     if (i < n) {
         id = oid[i];
         if (id & SPH_ID_GHOST) {
-            if (!(id & SPH_ID_DEAD)) oid[i] = id | SPH_ID_DEAD;
+            if (!COUNT_ONLY && !(id & SPH_ID_DEAD)) oid[i] = id | SPH_ID_DEAD;
         } else {
             p = posm[i];
             moveL = p.x < lo;
             moveR = p.x >= hi;
             sendL = p.x < lo + halo;
             sendR = p.x >= hi - halo;
-            if (moveL || moveR) oid[i] = id | SPH_ID_GHOST; // kept as a ghost for this step
+            if (!COUNT_ONLY && (moveL || moveR)) oid[i] = id | SPH_ID_GHOST; // this step's ghost
         }
     }
 #pragma unroll
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void k_slab_pack(
             if (mm) atomicAdd(&counters[2 + side], (uint32_t)__popcll(mm));
         }
         base = (uint32_t)bcast_i((int)base, 0);
-        if (send) {
+        if (!COUNT_ONLY && send) {
             const uint32_t slot = base + mbcnt64(m);
             if (slot < (uint32_t)cap) {
                 float4 *dst = (side ? right : left) + 2 * (size_t)slot;

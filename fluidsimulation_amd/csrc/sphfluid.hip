@@ -118,7 +118,6 @@ struct SphCtx {
     DevBuf<uint32_t> tileList, tileCtl; // non-empty tiles; [0] their number, [1]/[2] work queues
     int nbGrid[4] = {0, 0, 0, 0};        // persistent grid of k_neighbors<FORCE,COUNT>
     int queueNext = 1;                   // next unused work-queue slot of tileCtl
-    int ablate = 0;                      // profiling switch (env SPH_ABLATE, read at sph_create)
     int fallbackCap = -1; // debug: LDS record cap override for the neighbour kernels
 
     // boundary
@@ -224,6 +223,27 @@ struct StageTimer {
         c->pending.push_back(ep);
     }
 };
+
+// A host that enables timings and never reads them must not grow the event pool without bound:
+// once a few hundred pairs are pending, the finished ones (in stream order) are folded into the
+// totals and their events recycled.
+void drain_timings(SphCtx *c)
+{
+    if (c->pending.size() < 512) return;
+    size_t done = 0;
+    while (done < c->pending.size() && hipEventQuery(c->pending[done].b) == hipSuccess) {
+        const EventPair &ep = c->pending[done];
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+            c->tm.ms[ep.stage] += ms;
+            c->tm.launches[ep.stage] += 1;
+        }
+        c->freeEvents.push_back(ep.a);
+        c->freeEvents.push_back(ep.b);
+        done++;
+    }
+    c->pending.erase(c->pending.begin(), c->pending.begin() + (long)done);
+}
 
 int collect_timings(SphCtx *c)
 {
@@ -546,9 +566,18 @@ int prepare_boundary(SphCtx *c)
     return SPH_OK;
 }
 
+// HIP's current device is thread-local: every entry point that may allocate, launch or copy makes
+// the context's device current first (a host may call from any thread)
+int use_device(SphCtx *c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    return SPH_OK;
+}
+
 int check_params(SphCtx *c, const SphParams *p)
 {
     if (!c) return SPH_E_INVALID;
+    if (int rc = use_device(c)) return rc;
     if (!p) return fail(c, SPH_E_INVALID, "params is NULL");
     if (!(p->gridSize > 0.f) || !std::isfinite(p->gridSize))
         return fail(c, SPH_E_INVALID, "gridSize must be positive and finite");
@@ -628,7 +657,6 @@ int sph_create(const SphConfig *cfg, SphCtx **out)
     }
     if (cfg && cfg->maxCells > 0) c->maxCells = std::max(cfg->maxCells, 64);
     c->timing = cfg && cfg->enableTimings;
-    if (const char *e = getenv("SPH_ABLATE")) c->ablate = atoi(e); // tools/ablate.sh only
     *out = c;
     return SPH_OK;
 }
@@ -638,6 +666,21 @@ int sph_destroy(SphCtx *c)
     if (!c) return SPH_E_INVALID;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+#ifdef NB_STAMPS
+    {
+        unsigned long long h[16];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)) == hipSuccess) {
+            const char *names[8] = {"lookup", "sizes", "scan", "offsets", "stage-issue", "stage-wait", "units", "units-wait"};
+            for (int k = 0; k < 2; k++) {
+                double tot = 0;
+                for (int i = 0; i < 8; i++) tot += (double)h[8 * k + i];
+                fprintf(stderr, "%s:", k ? "force" : "density");
+                for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * h[8 * k + i] / (tot > 0 ? tot : 1));
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+#endif
     for (int i = 0; i < 2; i++) {
         release(c->posm[i]); release(c->velq[i]); release(c->mat[i]); release(c->oid[i]);
     }
@@ -681,6 +724,7 @@ int sph_set_debug(SphCtx *c, int32_t flags)
 int sph_synchronize(SphCtx *c)
 {
     if (!c) return SPH_E_INVALID;
+    if (int rc_ = use_device(c)) return rc_;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPH_OK;
 }
@@ -756,6 +800,7 @@ int sph_set_colliders(SphCtx *c, const SphBox *boxes, int32_t K)
 int sph_get_colliders(SphCtx *c, SphBox *out, int32_t K)
 {
     if (!c || !out) return SPH_E_INVALID;
+    if (int rc_ = use_device(c)) return rc_;
     if (K != c->nboxes) return fail(c, SPH_E_INVALID, "K=%d but %d colliders are set", K, c->nboxes);
     if (K == 0) return SPH_OK;
     HIPCHK(c, hipMemcpyAsync(out, c->boxState.p, sizeof(SphBox) * (size_t)K, hipMemcpyDeviceToHost,
@@ -844,6 +889,7 @@ int sph_upload(SphCtx *c, const float *pos, const float *vel, const float *invMa
 int sph_download(SphCtx *c, float *pos_out, float *vel_out)
 {
     if (!c) return SPH_E_INVALID;
+    if (int rc_ = use_device(c)) return rc_;
     if (c->n <= 0) return fail(c, SPH_E_INVALID, "no particles uploaded");
     if (c->slab) return fail(c, SPH_E_INVALID, "slab mode: use sph_slab_download");
     const int N = c->n;
@@ -896,6 +942,7 @@ int sph_hash_position(SphCtx *c, const SphParams *p)
 int sph_radix_sort(SphCtx *c)
 {
     if (!c) return SPH_E_INVALID;
+    if (int rc_ = use_device(c)) return rc_;
     if (!c->haveKeys) return fail(c, SPH_E_INVALID, "sph_radix_sort before sph_hash_position");
     StageTimer t(c, SPH_T_SORT);
     // slab mode: dead ghosts carry key = cells, sort to the end and are cut off here
@@ -916,6 +963,7 @@ int sph_radix_sort(SphCtx *c)
 int sph_map_table(SphCtx *c)
 {
     if (!c) return SPH_E_INVALID;
+    if (int rc_ = use_device(c)) return rc_;
     if (!c->haveSort) return fail(c, SPH_E_INVALID, "sph_map_table before sph_radix_sort");
     int rc = ensure(c, c->table, (size_t)c->grid.cells);
     if (!rc) rc = ensure(c, c->ttable, (size_t)c->grid.tiles);
@@ -942,6 +990,7 @@ int sph_map_table(SphCtx *c)
 int sph_reorder(SphCtx *c)
 {
     if (!c) return SPH_E_INVALID;
+    if (int rc_ = use_device(c)) return rc_;
     if (!c->haveTable) return fail(c, SPH_E_INVALID, "sph_reorder before sph_map_table");
     if (c->ordered) return SPH_OK;
     StageTimer t(c, SPH_T_REORDER);
@@ -981,7 +1030,12 @@ static NbArgs neighbor_args(SphCtx *c, const SphParams *p, int cap)
     A.gy = p->gravity[1];
     A.gz = p->gravity[2];
     A.cap = c->fallbackCap >= 0 ? std::min(c->fallbackCap, cap) : cap;
-    A.ablate = c->ablate;
+    // window tails may read on into the next cells of the row only if no support radius exceeds
+    // the cell size (then those records are farther than h from every target of the cell)
+    A.overread = 1;
+    for (const Mat &m : c->mats)
+        if (!(m.h <= c->grid.cellSize)) A.overread = 0;
+    A.nmats = (int)c->mats.size();
     A.tileList = c->tileList.p;
     A.tileCtl = c->tileCtl.p;
     return A;
@@ -1120,6 +1174,7 @@ int sph_step_resident(SphCtx *c, const SphParams *p, int32_t nsteps)
     const bool fuse = !c->slab && !(c->debug & SPH_DEBUG_HASHES);
     bool keysReady = false;
     for (int s = 0; s < nsteps; s++) {
+        if (c->timing) drain_timings(c);
         if (keysReady) {
             if ((rc = sync_params(c, p))) return rc;
             c->haveKeys = true;
@@ -1282,6 +1337,7 @@ int sph_read(SphCtx *c, int32_t buffer, void *out, size_t bytes)
 int sph_find_bounds(SphCtx *c, float gridSize, float mn[3], float mx[3])
 {
     if (!c || !mn || !mx) return SPH_E_INVALID;
+    if (int rc_ = use_device(c)) return rc_;
     if (c->n <= 0) return fail(c, SPH_E_INVALID, "no particles uploaded");
     int rc = bounds_of(c, c->posm[c->cur].p, c->n, mn, mx);
     if (rc) return rc;
@@ -1373,6 +1429,7 @@ int sph_sort_pairs_noalloc(SphCtx *c, const uint32_t *keys_dev, int32_t n, int32
 int sph_get_timings(SphCtx *c, SphTimings *out)
 {
     if (!c || !out) return SPH_E_INVALID;
+    if (int rc_ = use_device(c)) return rc_;
     int rc = collect_timings(c);
     if (rc) return rc;
     *out = c->tm;
@@ -1382,6 +1439,7 @@ int sph_get_timings(SphCtx *c, SphTimings *out)
 int sph_reset_timings(SphCtx *c)
 {
     if (!c) return SPH_E_INVALID;
+    if (int rc_ = use_device(c)) return rc_;
     int rc = collect_timings(c);
     if (rc) return rc;
     std::memset(&c->tm, 0, sizeof(c->tm));
@@ -1393,6 +1451,7 @@ int sph_seed_volume(SphCtx *c, const float localToWorld[12], const float boundsM
                     float invMass, float gridSize, int32_t append, int32_t *added)
 {
     if (!c || !localToWorld || !boundsMin || !boundsSize || !params || !added) return SPH_E_INVALID;
+    if (int rc_ = use_device(c)) return rc_;
     if (c->slab) return fail(c, SPH_E_INVALID, "sph_seed_volume is not available in slab mode");
     if (!(radius > 0.f) || !(invMass > 0.f) || !(gridSize > 0.f) || !std::isfinite(gridSize))
         return fail(c, SPH_E_INVALID, "radius, invMass and gridSize must be positive");
@@ -1540,25 +1599,40 @@ int sph_slab_pack(SphCtx *c, float xlo, float xhi, float halo, void *left_dev, v
         return fail(c, SPH_E_INVALID, "sph_slab_pack: bad buffers");
     if (!(halo >= 0.f) || !(xlo <= xhi)) return fail(c, SPH_E_INVALID, "sph_slab_pack: bad slab");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemsetAsync(c->slabCounters.p, 0, 16, c->stream));
+    // sizing pass first: an exchange buffer that is too small is reported with the counts it
+    // would need and with nothing packed, flagged or re-counted, so the caller can grow it and
+    // call again
     const int cur = c->cur;
-    if (c->n > 0)
-        k_slab_pack<<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
-            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
-            (float4 *)left_dev, (float4 *)right_dev, capRecords, c->slabCounters.p);
-    HIPCHK(c, hipGetLastError());
-    uint32_t h[4];
-    HIPCHK(c, hipMemcpyAsync(h, c->slabCounters.p, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 4; i++) counts[i] = (int32_t)h[i];
+    uint32_t h[4] = {0, 0, 0, 0};
+    for (int pass = 0; pass < 2 && c->n > 0; pass++) {
+        HIPCHK(c, hipMemsetAsync(c->slabCounters.p, 0, 16, c->stream));
+        if (pass == 0)
+            k_slab_pack<true><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
+                c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
+                nullptr, nullptr, 0, c->slabCounters.p);
+        else
+            k_slab_pack<false><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
+                c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
+                (float4 *)left_dev, (float4 *)right_dev, capRecords, c->slabCounters.p);
+        HIPCHK(c, hipGetLastError());
+        if (pass == 0) {
+            HIPCHK(c, hipMemcpyAsync(h, c->slabCounters.p, 16, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int i = 0; i < 4; i++) counts[i] = (int32_t)h[i];
+            if (h[0] > (uint32_t)capRecords || h[1] > (uint32_t)capRecords)
+                return fail(c, SPH_E_TOOLARGE, "exchange buffer too small: %u / %u records, "
+                            "capacity %d (nothing was packed; counts[] holds what is needed)",
+                            h[0], h[1], capRecords);
+        }
+    }
+    if (c->n <= 0)
+        for (int i = 0; i < 4; i++) counts[i] = 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // the caller sends the buffers from its own stream
     // last step's ghosts are dead now; the particles that left stay as this step's ghosts
     const int moved = (int)(h[2] + h[3]);
     c->nDead += c->nGhost;
     c->nGhost = moved;
     c->nOwned -= moved;
-    if (h[0] > (uint32_t)capRecords || h[1] > (uint32_t)capRecords)
-        return fail(c, SPH_E_TOOLARGE, "exchange buffer too small: %u / %u records, capacity %d",
-                    h[0], h[1], capRecords);
     return SPH_OK;
 }
 
@@ -1569,11 +1643,20 @@ int sph_slab_import(SphCtx *c, const void *records_dev, int32_t count, int32_t t
     if (count < 0 || transfers < 0 || transfers > count || (count > 0 && !records_dev))
         return fail(c, SPH_E_INVALID, "sph_slab_import: bad arguments");
     if (count == 0) return SPH_OK;
-    if ((long long)c->n + count > c->slabCap)
-        return fail(c, SPH_E_TOOLARGE, "slab capacity %d exceeded (%d + %d records)", c->slabCap,
-                    c->n, count);
+    if ((long long)c->n + count > (1ll << 30))
+        return fail(c, SPH_E_TOOLARGE, "slab beyond 2^30 records (%d + %d)", c->n, count);
     HIPCHK(c, hipSetDevice(c->device));
     const int cur = c->cur, n = c->n;
+    if (n + count > c->slabCap) { // grow, keeping the resident records
+        const size_t want = (size_t)(n + count) + (size_t)(n + count) / 4 + 1024;
+        int rc = grow_keep(c, c->posm[cur], want, (size_t)n);
+        if (!rc) rc = grow_keep(c, c->velq[cur], want, (size_t)n);
+        if (!rc) rc = grow_keep(c, c->mat[cur], want, (size_t)n);
+        if (!rc) rc = grow_keep(c, c->oid[cur], want, (size_t)n);
+        if (!rc) rc = ensure_fluid(c, (int)want);
+        if (rc) return rc;
+        c->slabCap = (int)want;
+    }
     k_slab_import<<<blocks_for(count, 256), 256, 0, c->stream>>>(
         (const float4 *)records_dev, count, c->dmats.p, (int)c->mats.size(), c->posm[cur].p + n,
         c->velq[cur].p + n, c->mat[cur].p + n, c->oid[cur].p + n);

@@ -380,8 +380,10 @@ class Context:
 
     def slab_pack(self, xlo, xhi, halo, left_ptr, right_ptr, cap_records):
         counts = (C.c_int32 * 4)()
-        self._chk(self.lib.sph_slab_pack(self.h, xlo, xhi, halo, left_ptr, right_ptr, cap_records,
-                                         C.byref(counts)))
+        rc = self.lib.sph_slab_pack(self.h, xlo, xhi, halo, left_ptr, right_ptr, cap_records,
+                                    C.byref(counts))
+        self.last_slab_pack_counts = list(counts)   # on SPH_E_TOOLARGE: what the buffers need
+        self._chk(rc)
         return list(counts)
 
     def slab_import(self, records_ptr, count, transfers):

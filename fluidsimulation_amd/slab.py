@@ -104,12 +104,31 @@ class HipSlabBackend:
         self.dynamic_bodies = bool(dynamic_bodies)
         self.device = torch.device(device)
         self.cap = int(buffer_records)
+        self._alloc(self.cap)
+        self._keep = []        # received buffers the library may still be reading
+
+    def _alloc(self, cap):
+        self.cap = int(cap)
         self.left = torch.empty((self.cap, RECORD_FLOATS), dtype=torch.float32, device=self.device)
         self.right = torch.empty_like(self.left)
 
     def pack(self, xlo, xhi, halo):
-        counts = self.ctx.slab_pack(xlo, xhi, halo, self.left.data_ptr(), self.right.data_ptr(),
-                                    self.cap)
+        # sph_slab_pack synchronises the library's stream before it touches anything: every
+        # kernel that read last step's received buffers has finished by the time it returns
+        try:
+            counts = self.ctx.slab_pack(xlo, xhi, halo, self.left.data_ptr(),
+                                        self.right.data_ptr(), self.cap)
+        except native.SphError as e:
+            if e.code != native.SPH_E_TOOLARGE:
+                raise
+            # nothing was packed or re-flagged: size the buffers from the reported counts (the
+            # torch stream is idle here: exchange() ends with a synchronise) and pack again
+            need = self.ctx.last_slab_pack_counts
+            torch.cuda.current_stream(self.device).synchronize()
+            self._alloc(max(need[0], need[1]) * 3 // 2 + 64)
+            counts = self.ctx.slab_pack(xlo, xhi, halo, self.left.data_ptr(),
+                                        self.right.data_ptr(), self.cap)
+        self._keep.clear()
         return self.left[:counts[0]], self.right[:counts[1]], counts
 
     def import_records(self, records, transfers):
@@ -119,7 +138,7 @@ class HipSlabBackend:
         # the library reads the buffer on its own stream: the producer (torch) must be done
         torch.cuda.current_stream(self.device).synchronize()
         self.ctx.slab_import(records.data_ptr(), records.shape[0], transfers)
-        self._keep = records   # stays alive until the next pack has synchronised the stream
+        self._keep.append(records)   # alive until the next pack has synchronised the stream
 
     def step(self):
         self.ctx.step_resident(self.params, 1)
@@ -235,6 +254,10 @@ class SlabSimulation:
                 req.wait()
         if self.stage_on_host:
             result = [(buf.to(left.device), t) for buf, t in result]
+        elif left.is_cuda:
+            # NCCL requests complete in stream order only: the next pack (on the library's own
+            # stream) must not overwrite a send buffer that is still in flight
+            torch.cuda.current_stream(left.device).synchronize()
         return result
 
     def exchange(self):

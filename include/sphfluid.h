@@ -265,8 +265,9 @@ SPH_API int sph_reset_timings(SphCtx *ctx);
 
 /* Like sph_upload, with global particle ids (< 2^30, unique over all ranks) and an explicit
  * material table that must be identical on every rank: materials[5*m] = radius, restDensity,
- * viscosity, gasConstant, inverseMass; materialIndex[i] < M.  capacity = the most records
- * (owned + ghosts of two consecutive steps) the fluid buffers have to hold. */
+ * viscosity, gasConstant, inverseMass; materialIndex[i] < M.  capacity = room for records
+ * (owned + ghosts of two consecutive steps) allocated up front; an import that needs more grows
+ * the buffers (a reallocation and a copy: size it generously where that matters). */
 SPH_API int sph_slab_upload(SphCtx *ctx, const float *pos, const float *vel,
                             const uint32_t *materialIndex, const uint32_t *ids, int32_t N,
                             const float *materials, int32_t M, float gridSize, int32_t capacity);
@@ -275,7 +276,9 @@ SPH_API int sph_slab_upload(SphCtx *ctx, const float *pos, const float *vel,
  * ghost for this step), right <- x >= xhi - halo (x >= xhi: transfer).  Pass -INF / +INF on
  * the outer ranks.  counts = records left, records right, transfers left, transfers right.
  * The order of the records is not deterministic; the order of the particles after the next sort
- * is (cell, id).  Synchronises. */
+ * is (cell, id).  Synchronises.  If a side needs more than capRecords the call returns
+ * SPH_E_TOOLARGE with counts[] = what is needed and NOTHING packed or re-flagged: grow the buffers
+ * and call again. */
 SPH_API int sph_slab_pack(SphCtx *ctx, float xlo, float xhi, float halo, void *left_dev,
                           void *right_dev, int32_t capRecords, int32_t counts[4]);
 /* Appends `count` records from a DEVICE buffer; `transfers` of them carry no ghost bit (the

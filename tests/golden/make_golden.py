@@ -5,6 +5,11 @@ The reference holds no fixtures and cannot run here (C#/Unity), so these vectors
 repository's oracle against regressions and give the GPU tests oracle-independent data:
   demo_step0.npz   shipped scene (4800 + 4000): hashes, neighbour counts, rho, p, F, v after step
   jitter_block.npz 12x12x12 jittered block (seeded): same quantities
+  jitter_32k.npz   32x32x32 = 32 768 jittered block (SURVEY 8c fixture 3: knife-edge coverage)
+  demo_sort.npz    shipped scene on an explicit table: dense keys, stable permutation, sorted
+                   keys, the non-empty (key, start, end) rows of the cell table
+  demo_traj.npz    shipped scene (with its walls and the BuoyancyObject): positions, velocities
+                   and body state after 1, 10 and 100 steps
 Run from the repo root:  python tests/golden/make_golden.py
 """
 import os
@@ -31,7 +36,42 @@ def dump(name, sc):
                         fcnt=fcnt.astype(np.int16), dens=dens, pres=pres, forces=forces, vel=vel)
 
 
+DEMO_GRID = ((-13, -3, -8), (28, 16, 16))   # origin, dims of the explicit table of demo_sort
+
+
+def dump_sort(name, sc):
+    cells = O.quantize(sc.pos, sc.grid_size)
+    keys = O.dense_keys(cells, *DEMO_GRID)
+    perm, skeys = O.stable_sort(keys)
+    ncells = int(np.prod(DEMO_GRID[1]))
+    table = O.cell_table(skeys, ncells)
+    rows = np.flatnonzero(table[:, 1] > table[:, 0])
+    np.savez_compressed(os.path.join(HERE, name), keys=keys, perm=perm, skeys=skeys,
+                        table_rows=rows.astype(np.int32), table_vals=table[rows])
+
+
+def dump_traj(name, sc, marks=(1, 10, 100)):
+    pos, vel, boxes = sc.pos.copy(), sc.vel.copy(), sc.boxes.copy()
+    dt = float(scene.DT)
+    out = {}
+    for step in range(1, max(marks) + 1):
+        vel, dens, pres, forces = O.sph_step(pos, vel, sc.inv_mass, sc.params, sc.bpos,
+                                             sc.bparams, sc.grid_size, dt=dt)
+        pos, vel, imp = O.integrate_particles(pos, vel, sc.inv_mass, sc.params, boxes, dt)
+        boxes = O.integrate_bodies(boxes, imp, dt)
+        if step in marks:
+            out[f"pos{step}"], out[f"vel{step}"], out[f"boxes{step}"] = pos.copy(), vel.copy(), boxes.copy()
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
 if __name__ == "__main__":
+    big = scene.dam_break(32, 32, 32, jitter_seed=0x5EED0003)
+    big.vel = np.random.default_rng(4).normal(0, 1.0, big.pos.shape).astype(np.float32)
+    np.save(os.path.join(HERE, "jitter_32k_vel.npy"), big.vel.astype(np.float16))
+    big.vel = big.vel.astype(np.float16).astype(np.float32)
+    dump("jitter_32k.npz", big)
+    dump_sort("demo_sort.npz", scene.demo_scene())
+    dump_traj("demo_traj.npz", scene.demo_scene())
     dump("demo_step0.npz", scene.demo_scene())
     sc = scene.dam_break(12, 12, 12, jitter_seed=0x5EED0003)
     rng = np.random.default_rng(3)

@@ -151,11 +151,14 @@ def test_dynamic_box_receives_the_reaction(oracle):
     np.testing.assert_allclose(v[0, 1] - b[0, 11], 3.0, rtol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["demo_step0", "jitter_block"])
+@pytest.mark.parametrize("name", ["demo_step0", "jitter_block", "jitter_32k"])
 def test_oracle_matches_golden(oracle, name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     if name == "demo_step0":
         sc = scene.demo_scene()
+    elif name == "jitter_32k":
+        sc = scene.dam_break(32, 32, 32, jitter_seed=0x5EED0003)
+        sc.vel = np.load(os.path.join(GOLD, "jitter_32k_vel.npy")).astype(np.float32)
     else:
         sc = scene.dam_break(12, 12, 12, jitter_seed=0x5EED0003)
         sc.vel = np.load(os.path.join(GOLD, "jitter_block_vel.npy"))
@@ -169,3 +172,30 @@ def test_oracle_matches_golden(oracle, name):
     np.testing.assert_array_equal(vel, g["vel"])
     _, _, cnt = oracle.density_pressure(sc.pos, sc.inv_mass, sc.params, sc.bpos, sc.grid_size)
     np.testing.assert_array_equal(cnt, g["dcnt"])
+
+
+def test_oracle_matches_golden_sort_and_trajectory(oracle):
+    """the keys / permutation / table fixture and the 1 / 10 / 100-step trajectory of the shipped
+    scene (tests/golden/make_golden.py) are reproduced bit for bit by the oracle"""
+    from tests.golden.make_golden import DEMO_GRID
+    sc = scene.demo_scene()
+    g = np.load(os.path.join(GOLD, "demo_sort.npz"))
+    keys = oracle.dense_keys(oracle.quantize(sc.pos, sc.grid_size), *DEMO_GRID)
+    perm, skeys = oracle.stable_sort(keys)
+    np.testing.assert_array_equal(keys, g["keys"])
+    np.testing.assert_array_equal(perm, g["perm"])
+    np.testing.assert_array_equal(skeys, g["skeys"])
+    assert np.array_equal(np.sort(perm), np.arange(sc.n))
+    t = np.load(os.path.join(GOLD, "demo_traj.npz"))
+    pos, vel, boxes = sc.pos.copy(), sc.vel.copy(), sc.boxes.copy()
+    for step in range(1, 11):
+        vel, _, _, _ = oracle.sph_step(pos, vel, sc.inv_mass, sc.params, sc.bpos, sc.bparams,
+                                       sc.grid_size, dt=float(scene.DT))
+        pos, vel, imp = oracle.integrate_particles(pos, vel, sc.inv_mass, sc.params, boxes,
+                                                   float(scene.DT))
+        boxes = oracle.integrate_bodies(boxes, imp, float(scene.DT))
+        if step in (1, 10):
+            np.testing.assert_array_equal(pos, t[f"pos{step}"])
+            np.testing.assert_array_equal(vel, t[f"vel{step}"])
+            np.testing.assert_array_equal(boxes, t[f"boxes{step}"])
+    assert np.isfinite(t["pos100"]).all() and np.isfinite(t["vel100"]).all()

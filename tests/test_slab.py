@@ -137,10 +137,21 @@ def test_slab_error_paths():
         ctx.download()
     import torch
     rec = torch.zeros((8, 8), dtype=torch.float32, device="cuda:0")
-    with pytest.raises(native.SphError):           # more records than the capacity holds
-        ctx.slab_import(rec.data_ptr(), 8, 0)
+    with pytest.raises(native.SphError) as e:       # a send buffer that is too small: reported
+        ctx.slab_pack(1.0, 1.5, 2.0, rec.data_ptr(), rec.data_ptr(), 4)   # with nothing changed
+    assert e.value.code == native.SPH_E_TOOLARGE
+    need = ctx.last_slab_pack_counts
+    assert need[0] > 4 and need[1] > 4 and need[2] + need[3] > 0
+    assert ctx.slab_counts() == {"resident": sc.n, "owned": sc.n, "ghosts": 0, "dead": 0}
+    # more records than the capacity holds: the buffers grow and keep the resident records
+    rec[:, 0:3] = torch.tensor([0.3, 0.3, 0.3])
+    rec[:, 7] = (torch.arange(8, dtype=torch.int32) + ((0x3FFF0000 | (1 << 31)) - (1 << 32))).view(torch.float32)
+    torch.cuda.synchronize()
+    ctx.slab_import(rec.data_ptr(), 8, 0)
+    assert ctx.slab_counts() == {"resident": sc.n + 8, "owned": sc.n, "ghosts": 8, "dead": 0}
     # everything within the halo of an open-ended slab: nothing to send, nothing moves
-    assert ctx.slab_pack(-np.inf, np.inf, 2.0, rec.data_ptr(), rec.data_ptr(), 8) == [0, 0, 0, 0]
+    rec2 = torch.zeros((8, 8), dtype=torch.float32, device="cuda:0")
+    assert ctx.slab_pack(-np.inf, np.inf, 2.0, rec2.data_ptr(), rec2.data_ptr(), 8) == [0, 0, 0, 0]
     p = native.make_params(sc.grid_size)
     ctx.step_resident(p, 2)
     pos, vel, rho, pid = ctx.slab_download()

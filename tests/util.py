@@ -53,3 +53,20 @@ def run_to_force(ctx, p):
     ctx.reorder()
     ctx.compute_density_and_pressure(p)
     ctx.compute_force(p)
+
+
+def assert_close_elementwise(got, want, rtol=RTOL, floor=0.0, what=""):
+    """|got - want| <= rtol * max(|want|, floor), element by element: `floor` is the magnitude
+    below which a value is compared absolutely (rtol * floor) instead of relatively; it is stated
+    by the caller in physical units (e.g. 1 % of the kernel radius for coordinates)."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    tol = rtol * np.maximum(np.abs(want), floor)
+    err = np.abs(got - want)
+    bad = ~(err <= tol)
+    if np.any(bad):
+        i = int(np.argmax(err / np.maximum(tol, 1e-300)))
+        raise AssertionError(f"{what}: {int(bad.sum())} of {got.size} beyond {rtol:g} element-wise "
+                             f"(floor {floor:g}); worst at flat index {i}: got {got.flat[i]!r} "
+                             f"want {want.flat[i]!r}")

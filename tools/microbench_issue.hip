@@ -28,7 +28,8 @@
                          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]),           \
                            "+v"(a[5]), "+v"(a[6]), "+v"(a[7])                                    \
                          : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]),     \
-                           "v"(b[6]), "v"(b[7]));                                                \
+                           "v"(b[6]), "v"(b[7])                                                  \
+                         : "s20", "s21", "s22", "s23", "vcc", "scc");                            \
         }                                                                                        \
         unsigned long long t1 = __builtin_amdgcn_s_memtime();                                    \
         unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                                \
@@ -108,6 +109,33 @@ DEFSEQ(s_dens_x2, 18, DPAIR2("%0", "%1", "%2", "%3", "%4", "%5", "%6", "%7", "%1
 DEFSEQ(s_dens_max_serial, 20, DPAIRM("%0", "%4", "%5", "%6", "%12", "%13", "%14")
                               DPAIRM("%0", "%4", "%5", "%6", "%13", "%14", "%15"))
 
+// ---- do scalar instructions take vector issue slots?  8 fma alone, with 8 / 16 s_add between
+#define SA(r) "s_add_u32 " r ", " r ", 1\n"
+DEFSEQ(s_fma8, 8, F("%0","%0","%8","%9") F("%1","%1","%8","%9") F("%2","%2","%8","%9") F("%3","%3","%8","%9")
+                  F("%4","%4","%8","%9") F("%5","%5","%8","%9") F("%6","%6","%8","%9") F("%7","%7","%8","%9"))
+DEFSEQ(s_fma8_salu8, 8, F("%0","%0","%8","%9") SA("s20") F("%1","%1","%8","%9") SA("s21") F("%2","%2","%8","%9") SA("s22")
+                        F("%3","%3","%8","%9") SA("s23") F("%4","%4","%8","%9") SA("s20") F("%5","%5","%8","%9") SA("s21")
+                        F("%6","%6","%8","%9") SA("s22") F("%7","%7","%8","%9") SA("s23"))
+DEFSEQ(s_fma8_salu16, 8, F("%0","%0","%8","%9") SA("s20") SA("s21") F("%1","%1","%8","%9") SA("s22") SA("s23")
+                         F("%2","%2","%8","%9") SA("s20") SA("s21") F("%3","%3","%8","%9") SA("s22") SA("s23")
+                         F("%4","%4","%8","%9") SA("s20") SA("s21") F("%5","%5","%8","%9") SA("s22") SA("s23")
+                         F("%6","%6","%8","%9") SA("s20") SA("s21") F("%7","%7","%8","%9") SA("s22") SA("s23"))
+// 8 fma + 2 scalar compare-and-branch (never taken)
+DEFSEQ(s_fma8_br2, 8, F("%0","%0","%8","%9") F("%1","%1","%8","%9") F("%2","%2","%8","%9") F("%3","%3","%8","%9")
+                      "s_cmp_eq_u32 s20, 0x7fffffff\n s_cbranch_scc1 1f\n"
+                      F("%4","%4","%8","%9") F("%5","%5","%8","%9") F("%6","%6","%8","%9") F("%7","%7","%8","%9")
+                      "s_cmp_eq_u32 s21, 0x7fffffff\n s_cbranch_scc1 1f\n 1:\n")
+// 8 fma + s_nop / s_waitcnt that never waits
+DEFSEQ(s_fma8_wait4, 8, F("%0","%0","%8","%9") F("%1","%1","%8","%9") "s_waitcnt lgkmcnt(0)\n" F("%2","%2","%8","%9") F("%3","%3","%8","%9") "s_waitcnt lgkmcnt(0)\n"
+                        F("%4","%4","%8","%9") F("%5","%5","%8","%9") "s_waitcnt lgkmcnt(0)\n" F("%6","%6","%8","%9") F("%7","%7","%8","%9") "s_waitcnt lgkmcnt(0)\n")
+// v_cndmask with vcc / an SGPR pair, and right after the compare that feeds it
+DEFSEQ(s_cnd_vcc, 8, "v_cndmask_b32 %0, %8, %9, vcc\n v_cndmask_b32 %1, %8, %9, vcc\n v_cndmask_b32 %2, %8, %9, vcc\n v_cndmask_b32 %3, %8, %9, vcc\n"
+                     "v_cndmask_b32 %4, %8, %9, vcc\n v_cndmask_b32 %5, %8, %9, vcc\n v_cndmask_b32 %6, %8, %9, vcc\n v_cndmask_b32 %7, %8, %9, vcc\n")
+DEFSEQ(s_cnd_sgpr, 8, "v_cndmask_b32 %0, %8, %9, s[20:21]\n v_cndmask_b32 %1, %8, %9, s[20:21]\n v_cndmask_b32 %2, %8, %9, s[20:21]\n v_cndmask_b32 %3, %8, %9, s[20:21]\n"
+                      "v_cndmask_b32 %4, %8, %9, s[20:21]\n v_cndmask_b32 %5, %8, %9, s[20:21]\n v_cndmask_b32 %6, %8, %9, s[20:21]\n v_cndmask_b32 %7, %8, %9, s[20:21]\n")
+DEFSEQ(s_cmp_cnd, 8, "v_cmp_lt_f32 vcc, %8, %0\n v_cndmask_b32 %0, %8, %9, vcc\n v_cmp_lt_f32 vcc, %8, %1\n v_cndmask_b32 %1, %8, %9, vcc\n"
+                     "v_cmp_lt_f32 vcc, %8, %2\n v_cndmask_b32 %2, %8, %9, vcc\n v_cmp_lt_f32 vcc, %8, %3\n v_cndmask_b32 %3, %8, %9, vcc\n")
+
 typedef void (*kern_t)(float *, float, unsigned long long *);
 
 static void run(kern_t k, const char *name, int ni, int w, float *d, unsigned long long *clk)
@@ -146,6 +174,8 @@ int main()
     for (int w : {1, 2, 4, 8}) {
         R(s_alt2); R(s_pair2); R(s_trip2); R(s_alt4); R(s_fast_slow); R(s_ffs); R(s_rsq7); R(s_rsq3);
         R(s_dens_serial); R(s_dens_x2); R(s_dens_max_serial);
+        R(s_fma8); R(s_fma8_salu8); R(s_fma8_salu16); R(s_fma8_br2); R(s_fma8_wait4);
+        R(s_cnd_vcc); R(s_cnd_sgpr); R(s_cmp_cnd);
         printf("\n");
     }
     return 0;
