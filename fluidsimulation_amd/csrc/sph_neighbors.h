@@ -5,32 +5,46 @@
 // ComputeDensityAndPressure / ComputeForce (FluidSolver.compute:128-272), which walk the table
 // per thread and gather every neighbour from global memory.
 //
-// Mapping (DESIGN.md "neighbour kernels").  One 256-thread workgroup owns one TILE of 4x4x2
-// cells (the sort key groups particles by tile, sph_device.h) and works through it in BLOCKS:
-// the whole tile when its halo fits the LDS tile, else its eight 2x2x1 sub-blocks, else single
-// cells (the fluid compresses several-fold at the bottom of a deep tank), else -- for a cell whose
-// 27-cell neighbourhood still overflows -- the same walk straight from global memory.  Per block:
-//   1. one thread per cell of the block's halo (block + one cell on every side) turns the table
-//      entries fetched at kernel start into LDS offsets with a block scan;
-//   2. the halo's particles are copied into the LDS tile by LDS-DMA (global_load_lds_dwordx4: no
-//      VGPR staging, 64 records per wave-instruction), fluid then boundary per cell, x-runs
-//      contiguous; a particle is read from L2/HBM ~4.5 times per pass instead of 27 times; the
-//      per-target constants of the block's own particles are cached in LDS at the same time, so
-//      the compute phase touches no global memory until its stores;
-//   3. the block's cells are dealt to the four waves.  For a cell with T particles (the targets)
-//      the 64 lanes split as T targets x S = 64/T candidate slices; a lane keeps its target in
-//      VGPRs (every inner-loop operand is a VGPR: VALU ops with an SGPR or constant operand issue
-//      at about half rate on gfx950, tools/microbench_valu.hip) and walks the 9 LDS row windows
-//      (x-1..x+1 of one (y,z)) with stride S, four ds_read_b128 issued ahead of their use;
-//   4. per-target partial sums are folded over the S slices through a wave-private LDS strip.
+// Mapping (DESIGN.md "neighbour kernels").  The sort key groups particles by TILE of 4x4x2 cells
+// (sph_device.h).  A tile is worked through in BLOCKS: the whole tile when its halo (block + one
+// cell on every side) fits the LDS image, else halves (4x4x1, 4x2x1, 2x2x1), else single cells
+// (the fluid compresses several-fold at the bottom of a deep tank), else -- for a cell whose
+// 27-cell neighbourhood still overflows -- a walk straight from global memory.
+//
+// Plan once, execute twice.  All the integer bookkeeping of a block is the same for the density
+// and the force pass, and it is latency-bound work (table look-ups, scans, dependent LDS reads)
+// that the arithmetic kernels cannot hide.  k_plan does it once per step, one workgroup per
+// non-empty tile, and writes for every block a PLAN to global memory:
+//   hinfo   per halo cell: LDS record index, fluid start (global sorted index), fluid count,
+//           boundary start
+//   units   a UNIT is (cell, part): up to 32 targets of one cell, T of them x S = 64/T candidate
+//           slices over the lanes of one wave
+//   slots   a SLOT is one step of that wave through the candidates: lane (target u, slice s) reads
+//           the record at  slot entry + 16 s.  The nine (dy,dz) row windows of a cell (cells
+//           x-1..x+1, contiguous in the image) are walked one after the other.  In a window's
+//           last slot the slices past its end read the records that FOLLOW the window: when those
+//           are still records of the same image row (cell x+2 and beyond: farther than one cell
+//           from every target, so their weight clamps to exactly 0 as long as no support radius
+//           exceeds the cell size) the slot is an ordinary one (list A); otherwise it goes to
+//           list B, whose entries carry the number of valid slices, the other lanes read FAR
+//   tmat    material index per target;   rcell  halo cell per record
+// k_neighbors<FORCE> (persistent workgroups over the block list) then only moves bytes and
+// computes: the plan and the halo's particles come in by LDS-DMA (global_load_lds_dwordx4: no VGPR
+// staging, 64 records per wave-instruction; fluid then boundary per cell, x-runs contiguous, so a
+// particle is read from L2/HBM ~4.5 times per pass instead of 27 times), the waves take the units,
+// per-target partial sums are folded over the S slices with DPP adds.
 //
 // Arithmetic.  The production kernels are branch-free: density uses w/h2 = clamp(1 - d2/h2),
 // force uses (h-r)/h = clamp(1 - r/h), so candidates outside the support contribute exactly 0
 // and no per-pair predicate is evaluated (pairs within an ulp of the support radius contribute
-// O(ulp^2), far below the 1e-5 tolerance of BASELINE.json).  The COUNT variants additionally
-// evaluate the reference's predicates exactly -- fp32, non-contracted (this file is compiled
-// with -ffp-contract=off): d2 = (dx*dx + dy*dy) + dz*dz; density d2 < h2; force
-// length < h  <=>  d2 < thrF (Mat::thrF) and index != j -- so neighbour COUNTS are bit-exact.
+// O(ulp^2), far below the 1e-5 tolerance of BASELINE.json).  Every inner-loop operand is a VGPR
+// and the loop is made of the vector ALU's fast class (fma / mul / add / sub with clamp, neg and
+// inline-constant modifiers: ~2.4 cycles per wave64 instruction per SIMD; min / max / med3 /
+// compares / shifts / SGPR operands: ~4.2; scalar instructions take issue slots too --
+// profiles/r2_microbench_*.txt).  The COUNT variants additionally evaluate the reference's
+// predicates exactly -- fp32, non-contracted (this file is compiled with -ffp-contract=off):
+// d2 = (dx*dx + dy*dy) + dz*dz; density d2 < h2; force length < h  <=>  d2 < thrF (Mat::thrF)
+// and index != j -- so neighbour COUNTS are bit-exact.
 #pragma once
 #include "sph_device.h"
 
@@ -39,11 +53,12 @@
 #define NB_HY (SPH_TY + 2)
 #define NB_HZ (SPH_TZ + 2)
 #define NB_HCELLS (NB_HX * NB_HY * NB_HZ) // 144
+#define NB_PTHREADS 256 // workgroup size of the plan kernel
 #ifndef NB_DTHREADS
-#define NB_DTHREADS 256 // workgroup size of the density kernel: 4 workgroups (16 waves) per CU
+#define NB_DTHREADS 256 // workgroup size of the density kernel
 #endif
 #ifndef NB_FTHREADS
-#define NB_FTHREADS 512 // workgroup size of the force kernel: 3 workgroups (24 waves) per CU
+#define NB_FTHREADS 512 // workgroup size of the force kernel
 #endif
 #define NB_MAXWAVES 8
 #ifndef NB_DG
@@ -52,34 +67,28 @@
 #ifndef NB_FG
 #define NB_FG 2 // same, force
 #endif
-#ifndef NB_DCAP
-#define NB_DCAP 1440 // LDS records per block, density kernel (23 KB): 40 KB per workgroup in all
+#ifndef NB_CAP
+#define NB_CAP 1184 // LDS records per block (18.5 KB of positions, as much again of velocities)
 #endif
-#ifndef NB_FCAP
-#define NB_FCAP 1184 // LDS records per block, force kernel (2 x 18.5 KB): 53 KB per workgroup in all
-#endif
-#define NB_TCAP 384      // targets per block (per-target loop constant and material index in LDS)
-#ifndef NB_CHUNK
-#define NB_CHUNK 8 // tiles per work-queue request
-#endif
+#define NB_TCAP 384      // targets per block
 #define NB_MAXUNITS 64   // (cell, part) units per block
 #define NB_SLOTCAP 1408  // slot-table entries per block
+#define NB_MTAB 64       // materials whose loop constants are cached in LDS
+#define NB_POOL_PIECE 8192 // 16-byte units of plan pool a plan workgroup takes at a time (128 KB)
+#define NB_LIST_PIECE 16   // block-list entries it takes at a time
+#ifndef NB_CHUNK
+#define NB_CHUNK 4 // blocks per work-queue request
+#endif
 #ifndef NB_DLB
-#define NB_DLB 4 // waves per SIMD the density kernel's register allocation must allow
+#define NB_DLB 5 // waves per SIMD the density kernel's register allocation must allow
 #endif
 #ifndef NB_FLB
 #define NB_FLB 6 // same, force
 #endif
+#define NB_MASKWORDS 4    // hit-mask words per lane and unit (units of up to 128 slots)
+// largest plan: hinfo + units + slots
+#define NB_PLANMAX (NB_HCELLS * 16 + NB_MAXUNITS * 32 + NB_SLOTCAP * 4)
 
-// Per block, in LDS.  A UNIT is (cell, part): up to 32 targets of one cell, T of them x S = 64/T
-// candidate slices over the lanes of one wave.  A SLOT is one step of that wave through the
-// candidates: lane (target u, slice s) reads the record at  slot entry + 16 s.  The nine (dy,dz)
-// row windows of a cell (cells x-1..x+1, contiguous in the image) are walked one after the other.
-// In a window's last slot the slices past its end read the records that FOLLOW the window: when
-// those are still records of the same image row (cell x+2 and beyond: farther than one cell from
-// every target, so their weight clamps to exactly 0 as long as no support radius exceeds the cell
-// size) the slot is an ordinary one (list A); otherwise the slot goes to list B, whose entries
-// carry the number of valid slices and whose other lanes read the FAR record.
 struct UnitDesc {
     int tS;      // targets | slices << 8
     int nAB;     // slots of list A | slots of list B << 16
@@ -87,28 +96,40 @@ struct UnitDesc {
     int self;    // LDS record index of the first target
     int slotA;   // slot-table index of list A
     int slotB;   // slot-table index of list B
-    int tbase;   // ordinal of the first target in the block (index into tk / tmat)
-    int pad;
+    int pad0, pad1;
 };
-struct TileShared {
-    int fs[NB_HCELLS];        // tile halo: fluid start (global sorted index) of the cell
-    int fc[NB_HCELLS];        //            fluid count
-    int bs[NB_HCELLS];        //            boundary start
-    int bc[NB_HCELLS];        //            boundary count
-    int hmap[NB_HCELLS];      // block halo cell -> tile halo cell
-    int spref[NB_HCELLS + 1]; // LDS record index of the block halo cell's records (fluid, then boundary)
-    int4 cinfo[SPH_TCELLS];   // per block cell: targets, ordinal of first target, first unit, first slot
-    int4 cpart[SPH_TCELLS];   //                 parts, targets per part, slices, slots reserved
-    int2 cellf[SPH_TCELLS];   // per block cell: halo index in the tile, halo index in the block
-    UnitDesc unit[NB_MAXUNITS];
-    __attribute__((aligned(16))) uint32_t slottab[NB_SLOTCAP];
-    int scan[4 * NB_MAXWAVES];
-    float tk[NB_TCAP];                // per target: -1/h2 (density) or -1/h (force)
-    unsigned short tmat[NB_TCAP];     // per target: material index
-    unsigned char tcell[NB_TCAP];                               // target -> cell of the block
+// block list entry: x = plan offset in the pool (16-byte units), y = tile,
+// z = halo cells | units << 8 | block origin (tile-local) x << 16 | y << 20 | z << 24,
+// w = records | targets << 11 | slot entries << 20
+typedef int4 BlockHdr;
+
+// control words shared by the plan and the neighbour kernels (SphCtx::tileCtl)
+enum { NB_CTL_TILES = 0, NB_CTL_BLOCKS, NB_CTL_GCELLS, NB_CTL_POOL, NB_CTL_ERROR, NB_CTL_QUEUE0 };
+
+// the 6x6x4 halo of a tile as the tables give it
+struct HaloTab {
+    int fs[NB_HCELLS]; // fluid start (global sorted index) of the cell
+    int fc[NB_HCELLS]; // fluid count
+    int bs[NB_HCELLS]; // boundary start
+    int bc[NB_HCELLS]; // boundary count
 };
 
-// kernel arguments shared by both passes
+// LDS of the plan kernel
+struct PlanShared {
+    HaloTab h;
+    int hmap[NB_HCELLS];      // block halo cell -> tile halo cell
+    int spref[NB_HCELLS + 1]; // LDS record index of the block halo cell's records
+    int2 cellf[SPH_TCELLS];   // per block cell: halo index in the tile, halo index in the block
+    int4 cslot[SPH_TCELLS];   // per block cell: slices, first slot (list A), first slot past the range
+    int2 cwin[SPH_TCELLS][9]; // per cell and window: x = full slots | rest << 16 | tail in list A << 24,
+                              //                      y = offset in list A | index in list B << 16
+    int scan[4 * NB_MAXWAVES];
+    int alloc[2];             // plan offset, block index of the block being planned
+    uint32_t poolAt, poolEnd; // this workgroup's current piece of the pool (16-byte units)
+    uint32_t listAt, listEnd; // this workgroup's current run of block-list entries
+};
+
+// kernel arguments shared by the plan and both passes
 struct NbArgs {
     const float4 *posm;
     float4 *velq;
@@ -126,10 +147,17 @@ struct NbArgs {
     float gx, gy, gz;
     int cap;
     int overread; // 1: every support radius <= cell size, window tails may read on (list A)
+    int useMasks; // force pass: the density pass of this plan has written the hit masks
     int nmats;
-    const uint32_t *tileList; // non-empty tiles (k_map_table)
-    uint32_t *tileCtl;        // [0] number of tiles in the list, [queue] next list entry to take
-    int queue;
+    const uint32_t *tileList; // non-empty tiles (k_tile_list)
+    uint32_t *ctl;            // NB_CTL_* words and the work-queue counters
+    int queue;                // index of this launch's work-queue counter (two words: blocks, cells)
+    BlockHdr *blockList;
+    int blockCap;
+    int2 *gcellList;          // cells for the global-memory path: tile, x | y << 8 | z << 16
+    int gcellCap;
+    uint4 *pool;              // plans
+    uint32_t poolCap;         // in 16-byte units
 };
 
 __device__ __forceinline__ int wrapi(int c, int g) { return c < 0 ? c + g : (c >= g ? c - g : c); }
@@ -196,8 +224,24 @@ template <int N> __device__ __forceinline__ void fold_slices(float (&v)[N], int 
     }
 }
 
+#ifdef NB_STAMPS // experimental builds: cycles per phase, summed over workgroups (thread 0)
+static __device__ unsigned long long g_stamps[32];
+#define NB_STAMP0() unsigned long long stamp_ = __builtin_amdgcn_s_memtime()
+#define NB_STAMP(i)                                                                              \
+    do {                                                                                         \
+        if (threadIdx.x == 0) {                                                                  \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                        \
+            atomicAdd(&g_stamps[(i)], now_ - stamp_);                                            \
+            stamp_ = now_;                                                                       \
+        }                                                                                        \
+    } while (0)
+#else
+#define NB_STAMP0()
+#define NB_STAMP(i)
+#endif
+
 // exclusive scan of four values per thread over the workgroup; t = the four totals
-__device__ __forceinline__ void block_scan4(TileShared &sh, const int (&v)[4], int (&e)[4], int (&t)[4])
+__device__ __forceinline__ void block_scan4(int *scan, const int (&v)[4], int (&e)[4], int (&t)[4])
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int i4[4] = {v[0], v[1], v[2], v[3]};
@@ -209,10 +253,10 @@ __device__ __forceinline__ void block_scan4(TileShared &sh, const int (&v)[4], i
             if (lane >= d) i4[k] += x;
         }
     }
-    __syncthreads(); // previous users of sh.scan are done
+    __syncthreads(); // previous users of scan[] are done
     if (lane == 63)
 #pragma unroll
-        for (int k = 0; k < 4; k++) sh.scan[4 * w + k] = i4[k];
+        for (int k = 0; k < 4; k++) scan[4 * w + k] = i4[k];
     __syncthreads();
     int base[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -222,7 +266,7 @@ __device__ __forceinline__ void block_scan4(TileShared &sh, const int (&v)[4], i
         if (i >= nw) break;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int x = sh.scan[4 * i + k];
+            const int x = scan[4 * i + k];
             if (i < w) base[k] += x;
             t[k] += x;
         }
@@ -231,8 +275,8 @@ __device__ __forceinline__ void block_scan4(TileShared &sh, const int (&v)[4], i
     for (int k = 0; k < 4; k++) e[k] = base[k] + i4[k] - v[k];
 }
 
-// table look-ups for the 6x6x4 halo of the tile (once per workgroup)
-__device__ __forceinline__ void tile_lookup(TileShared &sh, int tile, const NbArgs &A)
+// table look-ups for the 6x6x4 halo of the tile
+__device__ __forceinline__ void tile_lookup(HaloTab &h, int tile, const NbArgs &A)
 {
     const GridDesc &g = A.g;
     const int tid = threadIdx.x;
@@ -245,10 +289,10 @@ __device__ __forceinline__ void tile_lookup(TileShared &sh, int tile, const NbAr
         const int2 f = A.table[k];
         int2 b = make_int2(0, 0);
         if (A.btable) b = A.btable[k];
-        sh.fs[tid] = f.x;
-        sh.fc[tid] = f.y - f.x;
-        sh.bs[tid] = b.x;
-        sh.bc[tid] = b.y - b.x;
+        h.fs[tid] = f.x;
+        h.fc[tid] = f.y - f.x;
+        h.bs[tid] = b.x;
+        h.bc[tid] = b.y - b.x;
     }
     __syncthreads();
 }
@@ -276,7 +320,7 @@ struct DensityTarget {
 };
 template <bool COUNT>
 __device__ __forceinline__ void density_pair(const DensityTarget &t, const float4 &c, float &acc,
-                                             int &cnt)
+                                             int &cnt, uint32_t &hits)
 {
     const float dx = t.x - c.x, dy = t.y - c.y, dz = t.z - c.z;
     if (COUNT) {
@@ -289,6 +333,8 @@ __device__ __forceinline__ void density_pair(const DensityTarget &t, const float
         const float w =
             __builtin_amdgcn_fmed3f(__builtin_fmaf(d2, t.negInvH2, 1.0f), 0.f, 1.0f); // w / h2
         acc = __builtin_fmaf(w * w, w, acc);
+        // hit mask for the force pass: hits = 2 hits + (w > 0), the newest slot in bit 0
+        asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(w) : "vcc");
     }
 }
 
@@ -344,9 +390,10 @@ template <bool COUNT> struct Pass<false, COUNT> {
     DensityTarget t;
     float acc = 0.f;
     int cnt = 0;
+    uint32_t hits = 0; // one bit per slot walked since the last flush (production variant)
     __device__ __forceinline__ void pair(const float4 &cp, const float4 &, bool)
     {
-        density_pair<COUNT>(t, cp, acc, cnt);
+        density_pair<COUNT>(t, cp, acc, cnt, hits);
     }
     // folds the slices and writes rho, p, q for target ti
     __device__ __forceinline__ void finish(const NbArgs &A, int S, int slice, bool writer, int ti,
@@ -372,6 +419,7 @@ template <bool COUNT> struct Pass<false, COUNT> {
 template <bool COUNT> struct Pass<true, COUNT> {
     ForceTarget t;
     ForceAcc a;
+    uint32_t hits = 0; // (unused: the force pass reads the masks)
     __device__ __forceinline__ void pair(const float4 &cp, const float4 &cv, bool notSelf)
     {
         force_pair<COUNT>(t, cp, cv, notSelf, a);
@@ -412,21 +460,6 @@ __device__ __forceinline__ float4 finish_constants(const NbArgs &A, int gi, uint
     return make_float4(0.f, COUNT ? m->poly6 : m->poly6h6, m->gasConstant, m->restDensity);
 }
 
-// ------------------------------------------------------------------------------------------
-#ifdef NB_STAMPS // experimental builds: cycles per phase, summed over workgroups (thread 0)
-static __device__ unsigned long long g_stamps[16];
-#define NB_STAMP(i)                                                                              \
-    do {                                                                                         \
-        if (threadIdx.x == 0) {                                                                  \
-            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                        \
-            atomicAdd(&g_stamps[(FORCE ? 8 : 0) + (i)], now_ - *stamp);                          \
-            *stamp = now_;                                                                       \
-        }                                                                                        \
-    } while (0)
-#else
-#define NB_STAMP(i)
-#endif
-
 // floor(a / b) for 0 <= a < 2^20, 1 <= b <= 64 without an integer division: (a + 0.5) / b is at
 // least 0.5/64 away from every integer, far more than the error of v_rcp
 __device__ __forceinline__ int div_small(int a, int b)
@@ -434,260 +467,9 @@ __device__ __forceinline__ int div_small(int a, int b)
     return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b));
 }
 
-// one block (bx0.., sx x sy x sz cells, tile-local) through the LDS tile.  Returns false, having
-// done nothing, when the block's halo, targets, units or slots do not fit.
-template <bool FORCE, bool COUNT, int sx, int sy, int sz>
-__device__ __forceinline__ bool process_block(TileShared &sh, float4 *recP, float4 *recV, float *tthr,
-                                              unsigned char *rcell, const NbArgs &A, int bx0,
-                                              int by0, int bz0, unsigned long long *stamp = nullptr)
-{
-    constexpr int NB_THREADS = FORCE ? NB_FTHREADS : NB_DTHREADS, NB_WAVES = NB_THREADS / 64;
-    constexpr int hxN = sx + 2, hyN = sy + 2, nh = hxN * hyN * (sz + 2), ncells = sx * sy * sz;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int cap = A.cap;
-
-    // 1. sizes: records per halo cell; targets, parts, slices and a bound on the slots per cell
-    int v4[4] = {0, 0, 0, 0}; // records, targets, units, slots
-    int P = 0, per = 0, S = 0;
-    if (tid < nh) {
-        const int hx = tid % hxN, hy = (tid / hxN) % hyN, hz = tid / (hxN * hyN);
-        const int f = tile_halo_index(bx0 + hx, by0 + hy, bz0 + hz);
-        sh.hmap[tid] = f;
-        v4[0] = sh.fc[f] + sh.bc[f];
-    }
-    if (tid < ncells) {
-        const int cx = tid % sx, cy = (tid / sx) % sy, cz = tid / (sx * sy);
-        const int f = tile_halo_index(bx0 + cx + 1, by0 + cy + 1, bz0 + cz + 1);
-        const int tcnt = sh.fc[f];
-        sh.cellf[tid] = make_int2(f, ((cz + 1) * hyN + (cy + 1)) * hxN + (cx + 1));
-        v4[1] = tcnt;
-        if (tcnt > 0) {
-            // at most 32 targets per unit (S >= 2), and at least as many units as waves
-            P = max((tcnt + 31) >> 5, min(tcnt, (NB_WAVES + ncells - 1) / ncells));
-            if (P == 1) {
-                per = tcnt;
-            } else {
-                per = div_small(tcnt, P);
-                while (per * P < tcnt) per++;
-                P = div_small(tcnt, per);
-                while (P * per < tcnt) P++;
-            }
-            S = slices_for(per);
-            int V = 0; // candidates: the records of the 27 cells
-#pragma unroll
-            for (int k = 0; k < 27; k++) {
-                const int f2 = f + ((k / 9) - 1) * (NB_HX * NB_HY) + (((k / 3) % 3) - 1) * NB_HX + (k % 3) - 1;
-                V += sh.fc[f2] + sh.bc[f2];
-            }
-            // sum over the 9 windows of ceil(len / S) <= (V + 9 (S - 1)) / S; a multiple of 4
-            v4[3] = (div_small(V + 9 * (S - 1), S) + 4) & ~3;
-            v4[2] = P;
-        }
-    }
-    int e4[4], t4[4];
-    NB_STAMP(1); // sizes
-    block_scan4(sh, v4, e4, t4);
-    NB_STAMP(2); // scan
-    const int total = t4[0], ttotal = t4[1], nunits = t4[2];
-    if (total > cap || ttotal > NB_TCAP || nunits > NB_MAXUNITS || t4[3] > NB_SLOTCAP) return false;
-    if (ttotal == 0) return true;
-    // besides the prefix sums, every record and every target gets the index of its cell (a byte
-    // each): the staging loops below then look it up instead of bisecting the prefix sums
-    if (tid < nh) {
-        sh.spref[tid] = e4[0];
-#pragma nounroll
-        for (int k = e4[0]; k < e4[0] + v4[0]; k++) rcell[k] = (unsigned char)tid;
-    }
-    if (tid == nh) sh.spref[nh] = total;
-    if (tid < ncells) {
-        sh.cinfo[tid] = make_int4(v4[1], e4[1], e4[2], e4[3]);
-        sh.cpart[tid] = make_int4(P, per, S, v4[3]);
-#pragma nounroll
-        for (int k = e4[1]; k < e4[1] + v4[1]; k++) sh.tcell[k] = (unsigned char)tid;
-    }
-    __syncthreads();
-    NB_STAMP(3); // offsets and cell maps
-
-    // 2. stage records (LDS-DMA), per-target loop constants, slot tables and unit descriptors
-    for (int q0 = 0; q0 < total; q0 += NB_THREADS) {
-        const int qw = q0 + w * 64; // first record of this wave-instruction (wave-uniform)
-        const int q = qw + lane;
-        if (q < total) {
-            const int hcell = rcell[q];
-            const int f = sh.hmap[hcell];
-            const int k = q - sh.spref[hcell], fc = sh.fc[f];
-            const float4 *gp, *gv;
-            if (k < fc) {
-                gp = A.posm + (sh.fs[f] + k);
-                gv = A.velq + (sh.fs[f] + k);
-            } else {
-                gp = A.bposm + (sh.bs[f] + (k - fc));
-                gv = A.zeros; // boundary: v = 0, q = 0
-            }
-            __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(recP + qw), 16, 0, 0);
-            if (FORCE) __builtin_amdgcn_global_load_lds((gptr_t)gv, (lptr_t)(recV + qw), 16, 0, 0);
-        }
-    }
-    for (int i = tid; i < ttotal; i += NB_THREADS) {
-        const int c = sh.tcell[i];
-        const int gi = sh.fs[sh.cellf[c].x] + (i - sh.cinfo[c].y);
-        const uint32_t mi = A.mat[gi];
-        float k, thr;
-        loop_constants<FORCE>(A.mats[mi], k, thr);
-        sh.tk[i] = k;
-        sh.tmat[i] = (unsigned short)mi;
-        if (COUNT) tthr[i] = thr;
-    }
-#ifdef NB_SKIP_TABLES
-    if (A.cap < 0)
-#endif
-    if (tid < ncells && v4[1] > 0) {
-        // the cell's slot lists: A from the front of its reserved range, B from the back
-        const int2 cf = sh.cellf[tid];
-        const int cx = tid % sx;
-        const int sbase = e4[3], send = e4[3] + v4[3];
-        int nA = 0, nB = 0;
-#pragma nounroll
-        for (int wi = 0; wi < 9; wi++) {
-            const int h0 = cf.y + ((wi / 3) - 1) * (hxN * hyN) + ((wi % 3) - 1) * hxN - 1;
-            const int ws = sh.spref[h0], we = sh.spref[h0 + 3];
-            const int rowEnd = sh.spref[h0 - cx + hxN];
-            const int len = we - ws;
-            const int nfull = div_small(len, S), rem = len - nfull * S;
-#pragma nounroll
-            for (int j = 0; j < nfull; j++) sh.slottab[sbase + nA++] = (uint32_t)((ws + j * S) * 16);
-            if (rem) {
-                const int tail = ws + nfull * S;
-                if (A.overread && tail + S <= rowEnd) sh.slottab[sbase + nA++] = (uint32_t)(tail * 16);
-                else sh.slottab[send - 1 - nB++] = (uint32_t)(tail * 16) | ((uint32_t)rem << 16);
-            }
-        }
-        const int cstart = sh.fs[cf.x], clds = sh.spref[cf.y];
-#pragma nounroll
-        for (int part = 0; part < P; part++) {
-            const int t0 = part * per;
-            UnitDesc u;
-            u.tS = min(per, v4[1] - t0) | (S << 8);
-            u.nAB = nA | (nB << 16);
-            u.gi0 = cstart + t0;
-            u.self = clds + t0;
-            u.slotA = sbase;
-            u.slotB = send - nB;
-            u.tbase = e4[1] + t0;
-            u.pad = 0;
-            sh.unit[e4[2] + part] = u;
-        }
-    }
-    if (tid == 0) {
-        recP[cap] = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f); // what masked lanes read
-        if (FORCE) recV[cap] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    NB_STAMP(4); // thread 0's own staging work issued
-    __syncthreads();
-    NB_STAMP(5); // waiting for the staging of the others (DMA, tables)
-
-    // 3. the units, dealt to the waves
-    const char *baseP = (const char *)recP, *baseV = (const char *)recV;
-    const char *slots = (const char *)sh.slottab;
-    const int far16 = cap * 16;
-#ifdef NB_SKIP_UNITS // experiment: staging cost alone
-    if (A.cap >= 0) { __syncthreads(); return true; }
-#endif
-    for (int unit = w; unit < nunits; unit += NB_WAVES) {
-        const UnitDesc ud = sh.unit[unit];
-        const int tS = uniform_i(ud.tS), nAB = uniform_i(ud.nAB);
-        const int T = tS & 0xff, S2 = tS >> 8, nA = nAB & 0xffff, nB = nAB >> 16;
-        int u, slice;
-        split_lane(lane, S2, u, slice);
-        const int slice16 = slice * 16;
-        const bool active = u < T;
-        const int tloc = active ? u : 0;
-        const int self16 = (ud.self + tloc) * 16; // LDS byte offset of the target itself
-        const int ti = ud.gi0 + tloc;
-        const bool writer = active && slice == 0;
-        Pass<FORCE, COUNT> ps;
-        // the target's finishing constants come from global memory (all slices of a target read
-        // the same words): loaded now, used after the walk
-        const float4 fc4 = finish_constants<FORCE, COUNT>(A, ti, sh.tmat[ud.tbase + tloc]);
-        {
-            const float4 tp = *(const float4 *)(baseP + self16);
-            ps.t.x = tp.x; ps.t.y = tp.y; ps.t.z = tp.z;
-        }
-        const float tkv = sh.tk[ud.tbase + tloc];
-        if constexpr (FORCE) {
-            const float4 tv = *(const float4 *)(baseV + self16);
-            ps.t.vx = tv.x; ps.t.vy = tv.y; ps.t.vz = tv.z;
-            ps.t.Pi = tv.w; // q_i = p_i / rho_i^2, written by the density kernel
-            ps.t.negInvH = tkv;
-            ps.t.tiny = 1.0e-30f;
-            ps.t.thrF = COUNT ? tthr[ud.tbase + tloc] : 0.f;
-        } else {
-            ps.t.negInvH2 = tkv;
-            ps.t.h2 = COUNT ? tthr[ud.tbase + tloc] : 0.f;
-        }
-        constexpr int G = FORCE ? NB_FG : NB_DG; // slots per iteration
-        // list A: lane reads entry + 16 * slice, nothing else per slot
-        const char *sp = slots + ud.slotA * 4;
-        int k = 0;
-        for (; k + G <= nA; k += G, sp += 4 * G) {
-            uint32_t e[G];
-            if constexpr (G == 4) {
-                const uint4 q = *(const uint4 *)sp;
-                e[0] = q.x; e[1] = q.y; e[2] = q.z; e[3] = q.w;
-            } else if constexpr (G == 2) {
-                const uint2 q = *(const uint2 *)sp;
-                e[0] = q.x; e[1] = q.y;
-            } else {
-#pragma unroll
-                for (int q = 0; q < G; q++) e[q] = ((const uint32_t *)sp)[q];
-            }
-            float4 cp[G], cv[G];
-            int off[G];
-#pragma unroll
-            for (int q = 0; q < G; q++) {
-                off[q] = (int)e[q] + slice16;
-                cp[q] = *(const float4 *)(baseP + off[q]);
-                if (FORCE) cv[q] = *(const float4 *)(baseV + off[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < G; q++) {
-                keep_b128(cp[q]);
-                if (FORCE) keep_b128x(cv[q]);
-                ps.pair(cp[q], cv[q], off[q] != self16);
-            }
-        }
-        for (; k < nA; k++, sp += 4) {
-            const int off = (int)*(const uint32_t *)sp + slice16;
-            const float4 cp = *(const float4 *)(baseP + off);
-            float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (FORCE) cv = *(const float4 *)(baseV + off);
-            keep_b128(cp);
-            if (FORCE) keep_b128x(cv);
-            ps.pair(cp, cv, off != self16);
-        }
-        // list B: slices at or past the entry's count read the FAR record
-        sp = slots + ud.slotB * 4;
-        for (int kb = 0; kb < nB; kb++, sp += 4) {
-            const uint32_t e = *(const uint32_t *)sp;
-            const int off = slice < (int)(e >> 16) ? (int)(e & 0xffffu) + slice16 : far16;
-            const float4 cp = *(const float4 *)(baseP + off);
-            float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (FORCE) cv = *(const float4 *)(baseV + off);
-            keep_b128(cp);
-            if (FORCE) keep_b128x(cv);
-            ps.pair(cp, cv, off != self16);
-        }
-        ps.finish(A, S2, slice, writer, ti, fc4);
-    }
-    NB_STAMP(6); // thread 0's wave: its units
-    __syncthreads(); // the LDS tile is reused by the next block
-    NB_STAMP(7); // waiting for the other waves' units
-    return true;
-}
-
 // one cell straight from global memory (its 27-cell neighbourhood overflows the LDS tile)
 template <bool FORCE, bool COUNT>
-__device__ void process_cell_global(TileShared &sh, const NbArgs &A, int lx, int ly, int lz)
+__device__ void process_cell_global(const HaloTab &sh, const NbArgs &A, int lx, int ly, int lz)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int f = tile_halo_index(lx + 1, ly + 1, lz + 1);
@@ -751,83 +533,491 @@ __device__ void process_cell_global(TileShared &sh, const NbArgs &A, int lx, int
     }
 }
 
-// ------------------------------------------------------------------------------------------
-template <bool FORCE, bool COUNT>
-__device__ __forceinline__ void process_tile(TileShared &sh, float4 *recP, float4 *recV, float *tthr,
-                                             unsigned char *rcell, const NbArgs &A, int tile)
-{
-    unsigned long long stamp_ = 0, *stamp = &stamp_;
-    (void)stamp;
-#ifdef NB_STAMPS
-    stamp_ = __builtin_amdgcn_s_memtime();
-#endif
-    tile_lookup(sh, tile, A);
-    NB_STAMP(0); // table look-ups
 
-    // The largest block whose 27-cell halo fits the LDS tile: the whole tile, then halves
-    // (4x4x1, 4x2x1, 2x2x1) down to single cells, then straight from global memory.  The 32
-    // cells are numbered so that every block is an aligned run: n = z*16 + (y/2)*8 + (x/2)*4 +
-    // (y&1)*2 + (x&1).
-    // (the whole-tile attempt is a call of its own so that its shape is a compile-time constant)
-    if (process_block<FORCE, COUNT, SPH_TX, SPH_TY, SPH_TZ>(sh, recP, recV, tthr, rcell, A, 0, 0, 0, stamp)) return;
-    int cursor = 0, size = SPH_TCELLS / 2;
-    while (cursor < SPH_TCELLS) {
-        const int bx = ((cursor >> 2) & 1) * 2 + (cursor & 1), by = ((cursor >> 3) & 1) * 2 + ((cursor >> 1) & 1),
-                  bz = cursor >> 4;
-        bool ok; // one instantiation per shape: the shape is a compile-time constant in each
-        switch (size) {
-        case 16: ok = process_block<FORCE, COUNT, 4, 4, 1>(sh, recP, recV, tthr, rcell, A, bx, by, bz, stamp); break;
-        case 8: ok = process_block<FORCE, COUNT, 4, 2, 1>(sh, recP, recV, tthr, rcell, A, bx, by, bz, stamp); break;
-        case 4: ok = process_block<FORCE, COUNT, 2, 2, 1>(sh, recP, recV, tthr, rcell, A, bx, by, bz, stamp); break;
-        default: ok = process_block<FORCE, COUNT, 1, 1, 1>(sh, recP, recV, tthr, rcell, A, bx, by, bz, stamp); break;
-        }
-        if (ok) {
-            cursor += size;
-        } else if (size > 1) {
-            size = size == 4 ? 1 : size >> 1;
-            continue;
-        } else {
-            process_cell_global<FORCE, COUNT>(sh, A, bx, by, bz);
-            __syncthreads();
-            cursor += 1;
-        }
-        const int low = cursor & -cursor; // largest aligned block at the new cursor
-        size = low >= 16 ? 16 : low >= 8 ? 8 : low >= 4 ? 4 : 1;
+// ------------------------------------------------------------------------------------------
+// PLAN KERNEL
+
+// the plan of one block (bx0.., sx x sy x sz cells, tile-local).  Returns false, having done
+// nothing, when the block's halo, targets, units or slots do not fit.  hinfo.z = fluid count |
+// boundary count << 16.
+template <int sx, int sy, int sz>
+__device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int tile, int bx0, int by0,
+                                           int bz0)
+{
+    constexpr int NT = NB_PTHREADS;
+    constexpr int hxN = sx + 2, hyN = sy + 2, nh = hxN * hyN * (sz + 2), ncells = sx * sy * sz;
+    const int tid = threadIdx.x;
+    const int cap = A.cap;
+    NB_STAMP0();
+
+    // 1. sizes: records per halo cell; targets, parts, slices and the slots of the nine windows
+    int v4[4] = {0, 0, 0, 0}; // records, targets, units, slots
+    int P = 0, per = 0, S = 0, myf = 0, nA = 0, nB = 0;
+    int2 wd[9];
+    if (tid < nh) {
+        const int hx = tid % hxN, hy = (tid / hxN) % hyN, hz = tid / (hxN * hyN);
+        myf = tile_halo_index(bx0 + hx, by0 + hy, bz0 + hz);
+        sh.hmap[tid] = myf;
+        v4[0] = sh.h.fc[myf] + sh.h.bc[myf];
     }
+    if (tid < ncells) {
+        const int cx = tid % sx, cy = (tid / sx) % sy, cz = tid / (sx * sy);
+        const int f = tile_halo_index(bx0 + cx + 1, by0 + cy + 1, bz0 + cz + 1);
+        const int tcnt = sh.h.fc[f];
+        sh.cellf[tid] = make_int2(f, ((cz + 1) * hyN + (cy + 1)) * hxN + (cx + 1));
+        v4[1] = tcnt;
+        if (tcnt > 0) {
+            // at most 32 targets per unit (S >= 2), and at least 8 units per block
+            P = max((tcnt + 31) >> 5, min(tcnt, (NB_MAXWAVES + ncells - 1) / ncells));
+            if (P == 1) {
+                per = tcnt;
+            } else {
+                per = div_small(tcnt, P);
+                while (per * P < tcnt) per++;
+                P = div_small(tcnt, per);
+                while (P * per < tcnt) P++;
+            }
+            S = slices_for(per);
+#pragma unroll
+            for (int wi = 0; wi < 9; wi++) {
+                // first cell of the window in the tile's halo (rows of NB_HX cells)
+                const int f0 = f + ((wi / 3) - 1) * (NB_HX * NB_HY) + ((wi % 3) - 1) * NB_HX - 1;
+                const int len = (sh.h.fc[f0] + sh.h.bc[f0]) + (sh.h.fc[f0 + 1] + sh.h.bc[f0 + 1]) +
+                                (sh.h.fc[f0 + 2] + sh.h.bc[f0 + 2]);
+                int rest = 0; // records of the same block row behind the window
+#pragma unroll
+                for (int x = 3; x < hxN; x++)
+                    if (cx + x < hxN) rest += sh.h.fc[f0 + x] + sh.h.bc[f0 + x];
+                const int nfull = div_small(len, S), rem = len - nfull * S;
+                const int tailA = (rem != 0 && A.overread && S - rem <= rest) ? 1 : 0;
+                const int tailB = (rem != 0 && !tailA) ? 1 : 0;
+                wd[wi] = make_int2(nfull | (rem << 16) | (tailA << 24), nA | (nB << 16));
+                nA += nfull + tailA;
+                nB += tailB;
+            }
+            v4[3] = (nA + nB + 3) & ~3;
+            v4[2] = P;
+        }
+    }
+    int e4[4], t4[4];
+    NB_STAMP(1);
+    block_scan4(sh.scan, v4, e4, t4);
+    NB_STAMP(2);
+    const int total = t4[0], ttotal = t4[1], nunits = t4[2], nslots = t4[3];
+    if (total > cap || ttotal > NB_TCAP || nunits > NB_MAXUNITS || nslots > NB_SLOTCAP) return false;
+    if (ttotal == 0) return true;
+    if (tid == 0) {
+        // Room for the plan and a place in the block list.  Both come out of pieces that the
+        // workgroup takes from the device-wide counters NB_POOL_PIECE / NB_LIST_PIECE at a time:
+        // one word serves only ~88 returning atomics per microsecond, one atomic per block would
+        // cost most of a millisecond per step.
+        const uint32_t units16 = (uint32_t)(nh * 16 + nunits * 32 + nslots * 4) >> 4;
+        if (sh.poolAt + units16 > sh.poolEnd) {
+            sh.poolAt = atomicAdd(&A.ctl[NB_CTL_POOL], (uint32_t)NB_POOL_PIECE);
+            sh.poolEnd = sh.poolAt + NB_POOL_PIECE;
+        }
+        if (sh.listAt == sh.listEnd) {
+            sh.listAt = atomicAdd(&A.ctl[NB_CTL_BLOCKS], (uint32_t)NB_LIST_PIECE);
+            sh.listEnd = sh.listAt + NB_LIST_PIECE;
+        }
+        const uint32_t off = sh.poolAt, idx = sh.listAt;
+        const bool ok = off + units16 <= A.poolCap && idx < (uint32_t)A.blockCap;
+        if (!ok) atomicOr(&A.ctl[NB_CTL_ERROR], 1u);
+        sh.poolAt += units16;
+        sh.listAt += 1;
+        sh.alloc[0] = ok ? (int)off : -1;
+        sh.alloc[1] = (int)idx;
+    }
+    if (tid < nh) sh.spref[tid] = e4[0];
+    if (tid == nh) sh.spref[nh] = total;
+    if (tid < ncells && v4[1] > 0) {
+        sh.cslot[tid] = make_int4(S, e4[3], e4[3] + v4[3], 0);
+#pragma unroll
+        for (int wi = 0; wi < 9; wi++) sh.cwin[tid][wi] = wd[wi];
+    }
+    __syncthreads();
+    NB_STAMP(3);
+
+    // 2. the plan goes straight to global memory: hinfo | units | slots
+    const int off = sh.alloc[0];
+    if (off >= 0) {
+        int4 *hinfoG = (int4 *)(A.pool + off);
+        UnitDesc *unitG = (UnitDesc *)(hinfoG + nh);
+        uint32_t *slotG = (uint32_t *)(unitG + nunits);
+        if (tid < nh)
+            hinfoG[tid] = make_int4(e4[0], sh.h.fs[myf], sh.h.fc[myf] | (sh.h.bc[myf] << 16), sh.h.bs[myf]);
+        if (tid < ncells && v4[1] > 0) {
+            const int2 cf = sh.cellf[tid];
+            const int cstart = sh.h.fs[cf.x], clds = sh.spref[cf.y];
+#pragma nounroll
+            for (int part = 0; part < P; part++) {
+                const int t0 = part * per;
+                UnitDesc u;
+                u.tS = min(per, v4[1] - t0) | (S << 8);
+                u.nAB = nA | (nB << 16);
+                u.gi0 = cstart + t0;
+                u.self = clds + t0;
+                u.slotA = e4[3];
+                u.slotB = e4[3] + v4[3] - nB;
+                u.pad0 = u.pad1 = 0;
+                unitG[e4[2] + part] = u;
+            }
+        }
+        // one task per (cell, window): its slots of list A from the front of the cell's range,
+        // its tail slot of list B (if any) from the back
+        for (int t = tid; t < ncells * 9; t += NT) {
+            const int c = t / 9, wi = t - c * 9;
+            const int4 cs = sh.cslot[c];
+            if (sh.h.fc[sh.cellf[c].x] == 0) continue;
+            const int2 wdv = sh.cwin[c][wi];
+            const int nfull = wdv.x & 0xffff, rem = (wdv.x >> 16) & 0xff, tailA = (wdv.x >> 24) & 1;
+            const int aoff = wdv.y & 0xffff, bidx = wdv.y >> 16;
+            const int h0 = sh.cellf[c].y + ((wi / 3) - 1) * (hxN * hyN) + ((wi % 3) - 1) * hxN - 1;
+            const int ws = sh.spref[h0], Sc = cs.x;
+            uint32_t *dst = slotG + cs.y + aoff;
+#pragma nounroll
+            for (int j = 0; j < nfull; j++) dst[j] = (uint32_t)((ws + j * Sc) * 16);
+            if (rem) {
+                const uint32_t tail = (uint32_t)((ws + nfull * Sc) * 16);
+                if (tailA) dst[nfull] = tail;
+                else slotG[cs.z - 1 - bidx] = tail | ((uint32_t)rem << 16);
+            }
+        }
+        if (tid == 0)
+            A.blockList[sh.alloc[1]] =
+                make_int4(off, tile, nh | (nunits << 8) | (bx0 << 16) | (by0 << 20) | (bz0 << 24),
+                          total | (ttotal << 11) | (nslots << 20));
+    }
+    NB_STAMP(4);
+    __syncthreads(); // the LDS tables are reused by the next block
+    NB_STAMP(5);
+    return true;
 }
 
-// Persistent workgroups: each takes the next non-empty tile from the list until it is exhausted
-// (every wave leaves through the same uniform test).  The grid is sized to what the chip holds, so
-// no workgroup is launched for the empty part of the table.
+// one workgroup per non-empty tile
+__global__ __launch_bounds__(NB_PTHREADS, 4) void k_plan(NbArgs A)
+{
+    __shared__ PlanShared sh;
+    if (threadIdx.x == 0) sh.poolAt = sh.poolEnd = sh.listAt = sh.listEnd = 0;
+    const uint32_t ntiles = A.ctl[NB_CTL_TILES];
+    for (uint32_t ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+        const int tile = (int)A.tileList[ti];
+        NB_STAMP0();
+        tile_lookup(sh.h, tile, A);
+        NB_STAMP(0);
+        // The largest block whose 27-cell halo fits the LDS image: the whole tile, then halves
+        // (4x4x1, 4x2x1, 2x2x1) down to single cells, then the global-memory path.  The 32 cells
+        // are numbered so that every block is an aligned run: n = z*16 + (y/2)*8 + (x/2)*4 +
+        // (y&1)*2 + (x&1).
+        if (plan_block<SPH_TX, SPH_TY, SPH_TZ>(sh, A, tile, 0, 0, 0)) continue;
+        int cursor = 0, size = SPH_TCELLS / 2;
+        while (cursor < SPH_TCELLS) {
+            const int bx = ((cursor >> 2) & 1) * 2 + (cursor & 1), by = ((cursor >> 3) & 1) * 2 + ((cursor >> 1) & 1),
+                      bz = cursor >> 4;
+            bool ok; // one instantiation per shape: the shape is a compile-time constant in each
+            switch (size) {
+            case 16: ok = plan_block<4, 4, 1>(sh, A, tile, bx, by, bz); break;
+            case 8: ok = plan_block<4, 2, 1>(sh, A, tile, bx, by, bz); break;
+            case 4: ok = plan_block<2, 2, 1>(sh, A, tile, bx, by, bz); break;
+            default: ok = plan_block<1, 1, 1>(sh, A, tile, bx, by, bz); break;
+            }
+            if (ok) {
+                cursor += size;
+            } else if (size > 1) {
+                size = size == 4 ? 1 : size >> 1;
+                continue;
+            } else {
+                if (threadIdx.x == 0 && sh.h.fc[tile_halo_index(bx + 1, by + 1, bz + 1)] > 0) {
+                    const uint32_t idx = atomicAdd(&A.ctl[NB_CTL_GCELLS], 1u);
+                    if (idx < (uint32_t)A.gcellCap) A.gcellList[idx] = make_int2(tile, bx | (by << 8) | (bz << 16));
+                    else atomicOr(&A.ctl[NB_CTL_ERROR], 2u);
+                }
+                cursor += 1;
+            }
+            const int low = cursor & -cursor; // largest aligned block at the new cursor
+            size = low >= 16 ? 16 : low >= 8 ? 8 : low >= 4 ? 4 : 1;
+        }
+        __syncthreads(); // sh.h is rewritten by the next tile
+    }
+    // the unused entries of this workgroup's last run of the block list: empty blocks
+    for (uint32_t i = sh.listAt + threadIdx.x; i < sh.listEnd; i += NB_PTHREADS)
+        if (i < (uint32_t)A.blockCap) A.blockList[i] = make_int4(0, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// NEIGHBOUR KERNELS
+
+template <bool FORCE, bool COUNT> struct NbShared {
+    __attribute__((aligned(16))) unsigned char plan[NB_PLANMAX]; // hinfo | units | slots | tmat | rcell
+    float4 recP[NB_CAP + 1];             // x, y, z, m_j (+ the FAR record)
+    float4 recV[FORCE ? NB_CAP + 1 : 1]; // vx, vy, vz, q_j = p_j/rho_j^2
+    float4 mtab[NB_MTAB];                // per material: -1/h2, -1/h, h2, thrF
+    BlockHdr hdr[NB_CHUNK];
+    uint32_t next;
+};
+static_assert(sizeof(HaloTab) <= NB_PLANMAX, "the global-memory path keeps the tile's halo in the plan area");
+
+// one planned block
+template <bool FORCE, bool COUNT>
+__device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbArgs &A, const BlockHdr hdr)
+{
+    constexpr int NT = FORCE ? NB_FTHREADS : NB_DTHREADS, NB_WAVES = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nh = hdr.z & 0xff, nunits = (hdr.z >> 8) & 0xff;
+    const int total = hdr.w & 0x7ff, ttotal = (hdr.w >> 11) & 0x1ff, nslots = (hdr.w >> 20) & 0xfff;
+    const int oUnits = nh * 16, oSlots = oUnits + nunits * 32, planBytes = oSlots + nslots * 4;
+    (void)ttotal;
+
+    NB_STAMP0();
+    // 1. the plan: one linear LDS-DMA copy
+    {
+        const char *src = (const char *)(A.pool + hdr.x);
+        for (int o0 = 0; o0 < planBytes; o0 += NT * 16) {
+            const int ow = o0 + w * 1024; // wave-uniform
+            if (ow + lane * 16 < planBytes)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + ow + lane * 16), (lptr_t)(sh.plan + ow), 16, 0, 0);
+        }
+    }
+    __syncthreads();
+    NB_STAMP((FORCE ? 16 : 8) + 0);
+
+    // 2. the records of the halo, fluid then boundary per cell.  Eight lanes per cell, eight
+    // cells per wave-instruction; every lane knows its source and its place in the image from the
+    // cell's hinfo alone.  All loads of a wave are issued before the first is waited for.
+    const int4 *hinfo = (const int4 *)sh.plan;
+    const UnitDesc *units = (const UnitDesc *)(sh.plan + oUnits);
+    float4 *recP = sh.recP, *recV = sh.recV;
+    {
+        constexpr int NG = (NB_HCELLS / 8 + NB_WAVES - 1) / NB_WAVES; // cell groups per wave
+        static_assert(NG <= 5, "five named register sets below");
+        const int k = lane & 7;
+        int more = 0;
+        // (named variables, not arrays: the register allocator keeps arrays with predicated
+        // writes in scratch memory)
+#define NB_LOAD_GROUP(g, RP, RV, DST)                                                            \
+        float4 RP = make_float4(0.f, 0.f, 0.f, 0.f), RV = RP;                                    \
+        int DST = -1;                                                                            \
+        if (g < NG) {                                                                            \
+            const int c = (w + g * NB_WAVES) * 8 + (lane >> 3);                                  \
+            if (c < nh) {                                                                        \
+                const int4 hi = hinfo[c];                                                        \
+                const int fc = hi.z & 0xffff, cnt = fc + (hi.z >> 16);                           \
+                more |= cnt > 8;                                                                 \
+                if (k < cnt) {                                                                   \
+                    DST = hi.x + k;                                                              \
+                    if (k < fc) {                                                                \
+                        RP = A.posm[hi.y + k];                                                   \
+                        if (FORCE) RV = A.velq[hi.y + k];                                        \
+                    } else {                                                                     \
+                        RP = A.bposm[hi.w + (k - fc)]; /* boundary: v = 0, q = 0 */              \
+                    }                                                                            \
+                }                                                                                \
+            }                                                                                    \
+        }
+#define NB_STORE_GROUP(RP, RV, DST)                                                              \
+        if (DST >= 0) {                                                                          \
+            recP[DST] = RP;                                                                      \
+            if (FORCE) recV[DST] = RV;                                                           \
+        }
+        NB_LOAD_GROUP(0, rp0, rv0, d0)
+        NB_LOAD_GROUP(1, rp1, rv1, d1)
+        NB_LOAD_GROUP(2, rp2, rv2, d2)
+        NB_LOAD_GROUP(3, rp3, rv3, d3)
+        NB_LOAD_GROUP(4, rp4, rv4, d4)
+        NB_STORE_GROUP(rp0, rv0, d0)
+        NB_STORE_GROUP(rp1, rv1, d1)
+        NB_STORE_GROUP(rp2, rv2, d2)
+        NB_STORE_GROUP(rp3, rv3, d3)
+        NB_STORE_GROUP(rp4, rv4, d4)
+#undef NB_LOAD_GROUP
+#undef NB_STORE_GROUP
+        if (__builtin_amdgcn_ballot_w64(more != 0)) { // cells with more than eight records
+            for (int g = 0; g < NG; g++) {
+                const int c = (w + g * NB_WAVES) * 8 + (lane >> 3);
+                if (c >= nh) continue;
+                const int4 hi = hinfo[c];
+                const int fc = hi.z & 0xffff, cnt = fc + (hi.z >> 16);
+                for (int k2 = k + 8; k2 < cnt; k2 += 8) {
+                    recP[hi.x + k2] = k2 < fc ? A.posm[hi.y + k2] : A.bposm[hi.w + (k2 - fc)];
+                    if (FORCE) recV[hi.x + k2] = k2 < fc ? A.velq[hi.y + k2] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    }
+    if (tid == 0) {
+        recP[NB_CAP] = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f); // what masked lanes read
+        if (FORCE) recV[NB_CAP] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // material index of this wave's first unit (the later ones are fetched one unit ahead)
+    uint32_t miNext = 0;
+    if (w < nunits) {
+        const UnitDesc u0 = units[w];
+        const int T0 = u0.tS & 0xff, S0 = u0.tS >> 8;
+        int u, sl;
+        split_lane(lane, S0, u, sl);
+        miNext = A.mat[u0.gi0 + (u < T0 ? u : 0)];
+    }
+    NB_STAMP((FORCE ? 16 : 8) + 1);
+    __syncthreads();
+    NB_STAMP((FORCE ? 16 : 8) + 2);
+
+    // 3. the units, dealt to the waves
+    const char *baseP = (const char *)recP, *baseV = (const char *)recV;
+    const char *slots = (const char *)sh.plan + oSlots;
+    const int far16 = NB_CAP * 16;
+    for (int unit = w; unit < nunits; unit += NB_WAVES) {
+        const UnitDesc ud = units[unit];
+        const int tS = uniform_i(ud.tS), nAB = uniform_i(ud.nAB);
+        const int T = tS & 0xff, S2 = tS >> 8, nA = nAB & 0xffff, nB = nAB >> 16;
+        int u, slice;
+        split_lane(lane, S2, u, slice);
+        const int slice16 = slice * 16;
+        const bool active = u < T;
+        const int tloc = active ? u : 0;
+        const int self16 = (ud.self + tloc) * 16; // LDS byte offset of the target itself
+        const int ti = ud.gi0 + tloc;
+        const bool writer = active && slice == 0;
+        Pass<FORCE, COUNT> ps;
+        const uint32_t mi = miNext;
+        if (unit + NB_WAVES < nunits) { // the next unit's material indices, used one unit later
+            const UnitDesc un = units[unit + NB_WAVES];
+            const int Tn = un.tS & 0xff, Sn = un.tS >> 8;
+            int u2, sl2;
+            split_lane(lane, Sn, u2, sl2);
+            miNext = A.mat[un.gi0 + (u2 < Tn ? u2 : 0)];
+        }
+        // the target's finishing constants come from global memory (all slices of a target read
+        // the same words): loaded now, used after the walk
+        const float4 fc4 = finish_constants<FORCE, COUNT>(A, ti, mi);
+        float4 mt;
+        if (mi < NB_MTAB) {
+            mt = sh.mtab[mi];
+        } else {
+            const Mat *m = A.mats + mi;
+            mt = make_float4(m->negInvH2, m->negInvH, m->h2, m->thrF);
+        }
+        {
+            const float4 tp = *(const float4 *)(baseP + self16);
+            ps.t.x = tp.x; ps.t.y = tp.y; ps.t.z = tp.z;
+        }
+        if constexpr (FORCE) {
+            const float4 tv = *(const float4 *)(baseV + self16);
+            ps.t.vx = tv.x; ps.t.vy = tv.y; ps.t.vz = tv.z;
+            ps.t.Pi = tv.w; // q_i = p_i / rho_i^2, written by the density kernel
+            ps.t.negInvH = mt.y;
+            ps.t.tiny = 1.0e-30f;
+            ps.t.thrF = mt.w;
+        } else {
+            ps.t.negInvH2 = mt.x;
+            ps.t.h2 = mt.z;
+        }
+        constexpr int G = FORCE ? NB_FG : NB_DG; // slots per iteration
+        // list A: lane reads entry + 16 * slice, nothing else per slot
+        const char *sp = slots + ud.slotA * 4;
+        int k = 0;
+        for (; k + G <= nA; k += G, sp += 4 * G) {
+            uint32_t e[G];
+            if constexpr (G == 4) {
+                const uint4 q = *(const uint4 *)sp;
+                e[0] = q.x; e[1] = q.y; e[2] = q.z; e[3] = q.w;
+            } else if constexpr (G == 2) {
+                const uint2 q = *(const uint2 *)sp;
+                e[0] = q.x; e[1] = q.y;
+            } else {
+#pragma unroll
+                for (int q = 0; q < G; q++) e[q] = ((const uint32_t *)sp)[q];
+            }
+            float4 cp[G], cv[G];
+            int off[G];
+#pragma unroll
+            for (int q = 0; q < G; q++) {
+                off[q] = (int)e[q] + slice16;
+                cp[q] = *(const float4 *)(baseP + off[q]);
+                if (FORCE) cv[q] = *(const float4 *)(baseV + off[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < G; q++) {
+                keep_b128(cp[q]);
+                if (FORCE) keep_b128x(cv[q]);
+                ps.pair(cp[q], cv[q], off[q] != self16);
+            }
+        }
+        for (; k < nA; k++, sp += 4) {
+            const int off = (int)*(const uint32_t *)sp + slice16;
+            const float4 cp = *(const float4 *)(baseP + off);
+            float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FORCE) cv = *(const float4 *)(baseV + off);
+            keep_b128(cp);
+            if (FORCE) keep_b128x(cv);
+            ps.pair(cp, cv, off != self16);
+        }
+        // list B: slices at or past the entry's count read the FAR record
+        sp = slots + ud.slotB * 4;
+        for (int kb = 0; kb < nB; kb++, sp += 4) {
+            const uint32_t e = *(const uint32_t *)sp;
+            const int off = slice < (int)(e >> 16) ? (int)(e & 0xffffu) + slice16 : far16;
+            const float4 cp = *(const float4 *)(baseP + off);
+            float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FORCE) cv = *(const float4 *)(baseV + off);
+            keep_b128(cp);
+            if (FORCE) keep_b128x(cv);
+            ps.pair(cp, cv, off != self16);
+        }
+        ps.finish(A, S2, slice, writer, ti, fc4);
+    }
+    NB_STAMP((FORCE ? 16 : 8) + 3);
+    __syncthreads(); // the LDS image and the plan are reused by the next block
+    NB_STAMP((FORCE ? 16 : 8) + 4);
+}
+
+// Persistent workgroups.  Blocks are taken from the list in chunks of NB_CHUNK through one
+// device-wide counter: a single word serves about 88 returning atomics per microsecond on this
+// chip, so one atomic per block would cost most of a millisecond per launch by itself; the next
+// chunk is requested while the current one is being processed.  Then the cells of the
+// global-memory path, one at a time.
 template <bool FORCE, bool COUNT>
 // second launch bound = waves per SIMD the register allocation must allow (what the LDS allows)
-__global__ __launch_bounds__(FORCE ? NB_FTHREADS : NB_DTHREADS, (FORCE ? NB_FLB : NB_DLB) - (COUNT ? 1 : 0))
+__global__ __launch_bounds__(FORCE ? NB_FTHREADS : NB_DTHREADS)
+__attribute__((amdgpu_waves_per_eu((FORCE ? NB_FLB : NB_DLB) - (COUNT ? 1 : 0), (FORCE ? NB_FLB : NB_DLB) - (COUNT ? 1 : 0))))
 void k_neighbors(NbArgs A)
 {
-    __shared__ TileShared sh;
-    __shared__ float4 recP[(FORCE ? NB_FCAP : NB_DCAP) + 1]; // x, y, z, m_j (+ the FAR record)
-    __shared__ float4 recV[FORCE ? NB_FCAP + 1 : 1];         // vx, vy, vz, q_j = p_j/rho_j^2
-    __shared__ float tthr[COUNT ? NB_TCAP : 1]; // COUNT variants: exact predicate threshold (h2 / thrF)
-    __shared__ unsigned char rcell[FORCE ? NB_FCAP : NB_DCAP]; // record -> halo cell of the block
-    __shared__ uint32_t next;
-    // Tiles are taken from the list in chunks of NB_CHUNK through one device-wide counter: a single
-    // word serves about 88 returning atomics per microsecond on this chip, so one atomic per
-    // tile (65 536 tiles on C3) would cost 0.75 ms per launch by itself.  The next chunk is
-    // requested while the current one is being processed.
-    const uint32_t ntiles = A.tileCtl[0];
+    __shared__ NbShared<FORCE, COUNT> sh;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NB_MTAB && i < A.nmats; i += blockDim.x) {
+        const Mat *m = A.mats + i;
+        sh.mtab[i] = make_float4(m->negInvH2, m->negInvH, m->h2, m->thrF);
+    }
+    const uint32_t nblocks = min(A.ctl[NB_CTL_BLOCKS], (uint32_t)A.blockCap);
     uint32_t pending = 0;
-    if (threadIdx.x == 0) pending = atomicAdd(&A.tileCtl[A.queue], (uint32_t)NB_CHUNK);
+    if (tid == 0) pending = atomicAdd(&A.ctl[A.queue], (uint32_t)NB_CHUNK);
     for (;;) {
-        if (threadIdx.x == 0) {
-            next = pending;
-            if (pending < ntiles) pending = atomicAdd(&A.tileCtl[A.queue], (uint32_t)NB_CHUNK);
+        if (tid == 0) {
+            sh.next = pending;
+            if (pending < nblocks) pending = atomicAdd(&A.ctl[A.queue], (uint32_t)NB_CHUNK);
         }
         __syncthreads();
-        const uint32_t first = next;
-        if (first >= ntiles) break;
-        const uint32_t last = min(first + (uint32_t)NB_CHUNK, ntiles);
-        // every thread has read `next` before thread 0 can write it again: each tile has barriers
-        for (uint32_t i = first; i < last; i++)
-            process_tile<FORCE, COUNT>(sh, recP, recV, tthr, rcell, A, (int)A.tileList[i]);
+        const uint32_t first = sh.next;
+        if (first >= nblocks) break;
+        const uint32_t n = min((uint32_t)NB_CHUNK, nblocks - first);
+        if (tid < (int)n) sh.hdr[tid] = A.blockList[first + tid];
+        __syncthreads();
+        // every thread has read `next` before thread 0 can write it again: each block has barriers
+        for (uint32_t i = 0; i < n; i++) {
+            const BlockHdr hdr = sh.hdr[i];
+            if (hdr.w != 0) exec_block<FORCE, COUNT>(sh, A, hdr); // (0: unused list entry)
+        }
+    }
+    // cells whose 27-cell neighbourhood overflows the LDS image
+    const uint32_t ncells = min(A.ctl[NB_CTL_GCELLS], (uint32_t)A.gcellCap);
+    HaloTab &ht = *(HaloTab *)sh.plan;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) sh.next = atomicAdd(&A.ctl[A.queue + 1], 1u);
+        __syncthreads();
+        const uint32_t i = sh.next;
+        if (i >= ncells) break;
+        const int2 gc = A.gcellList[i];
+        tile_lookup(ht, gc.x, A);
+        process_cell_global<FORCE, COUNT>(ht, A, gc.y & 0xff, (gc.y >> 8) & 0xff, (gc.y >> 16) & 0xff);
     }
 }

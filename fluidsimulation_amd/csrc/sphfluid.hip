@@ -115,9 +115,14 @@ struct SphCtx {
     GridDesc grid{};
     bool gridExplicit = false, gridValid = false;
     DevBuf<int2> table, btable, ttable;
-    DevBuf<uint32_t> tileList, tileCtl; // non-empty tiles; [0] their number, [1]/[2] work queues
+    DevBuf<uint32_t> tileList, tileCtl; // non-empty tiles; NB_CTL_* words and work-queue counters
     int nbGrid[4] = {0, 0, 0, 0};        // persistent grid of k_neighbors<FORCE,COUNT>
-    int queueNext = 1;                   // next unused work-queue slot of tileCtl
+    int queueNext = NB_CTL_QUEUE0;       // next unused pair of work-queue words of tileCtl
+    // neighbour plan (k_plan): block list, plans, cells of the global-memory path
+    DevBuf<BlockHdr> blockList;
+    DevBuf<int2> gcellList;
+    DevBuf<uint4> pool;
+    bool havePlan = false;
     int fallbackCap = -1; // debug: LDS record cap override for the neighbour kernels
 
     // boundary
@@ -668,14 +673,16 @@ int sph_destroy(SphCtx *c)
     (void)hipStreamSynchronize(c->stream);
 #ifdef NB_STAMPS
     {
-        unsigned long long h[16];
+        unsigned long long h[32];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)) == hipSuccess) {
-            const char *names[8] = {"lookup", "sizes", "scan", "offsets", "stage-issue", "stage-wait", "units", "units-wait"};
-            for (int k = 0; k < 2; k++) {
+            const char *pn[8] = {"lookup", "sizes", "scan", "alloc+offsets", "tmat+tables", "wait", "copy-out", "-"};
+            const char *en[8] = {"plan-dma", "rec-issue", "rec-wait", "units", "units-wait", "-", "-", "-"};
+            for (int k = 0; k < 3; k++) {
                 double tot = 0;
                 for (int i = 0; i < 8; i++) tot += (double)h[8 * k + i];
-                fprintf(stderr, "%s:", k ? "force" : "density");
-                for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * h[8 * k + i] / (tot > 0 ? tot : 1));
+                fprintf(stderr, "%s (%.3g Mcycles):", k == 0 ? "plan" : k == 1 ? "density" : "force", tot / 1e6);
+                for (int i = 0; i < 8; i++)
+                    if (h[8 * k + i]) fprintf(stderr, " %s %.1f%%", (k ? en : pn)[i], 100.0 * h[8 * k + i] / (tot > 0 ? tot : 1));
                 fprintf(stderr, "\n");
             }
         }
@@ -688,7 +695,7 @@ int sph_destroy(SphCtx *c)
     release(c->rho); release(c->prs); release(c->force); release(c->zeros); release(c->dcount); release(c->fcount);
     release(c->hashes); release(c->keysEcs); release(c->cells);
     release(c->io3a); release(c->io3b); release(c->io1); release(c->ioU);
-    release(c->dmats); release(c->table); release(c->btable); release(c->ttable); release(c->tileList); release(c->tileCtl);
+    release(c->dmats); release(c->table); release(c->btable); release(c->ttable); release(c->tileList); release(c->tileCtl); release(c->blockList); release(c->gcellList); release(c->pool);
     release(c->bpos3); release(c->bpar3); release(c->bposmIn); release(c->bposm);
     release(c->bkeysA); release(c->bkeysB); release(c->bvalsA); release(c->bvalsB);
     release(c->boxState); release(c->devBoxes); release(c->bodyImpulse);
@@ -718,6 +725,18 @@ int sph_set_debug(SphCtx *c, int32_t flags)
     if (!c) return SPH_E_INVALID;
     c->debug = flags;
     c->fallbackCap = (flags & SPH_DEBUG_NO_LDS_TILE) ? 0 : -1;
+    c->havePlan = false;
+    return SPH_OK;
+}
+
+// sticky device-side error word of the plan kernel (pool / list exhausted: sized never to happen)
+static int check_plan_error(SphCtx *c)
+{
+    if (!c->tileCtl.p) return SPH_OK;
+    uint32_t e = 0;
+    HIPCHK(c, hipMemcpyAsync(&e, c->tileCtl.p + NB_CTL_ERROR, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (e) return fail(c, SPH_E_TOOLARGE, "neighbour plan overflow (flags %u): results of the last step are incomplete", e);
     return SPH_OK;
 }
 
@@ -726,7 +745,7 @@ int sph_synchronize(SphCtx *c)
     if (!c) return SPH_E_INVALID;
     if (int rc_ = use_device(c)) return rc_;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SPH_OK;
+    return check_plan_error(c);
 }
 
 float sph_find_grid_size(const SphParticle *params, const int32_t *chunk_first, int32_t nchunks,
@@ -895,6 +914,7 @@ int sph_download(SphCtx *c, float *pos_out, float *vel_out)
     const int N = c->n;
     int rc = ensure(c, c->io3a, (size_t)3 * N);
     if (!rc) rc = ensure(c, c->io3b, (size_t)3 * N);
+    if (!rc) rc = check_plan_error(c);
     if (rc) return rc;
     const int cur = c->cur;
     if (pos_out) {
@@ -976,7 +996,8 @@ int sph_map_table(SphCtx *c)
     HIPCHK(c, hipMemsetAsync(c->table.p, 0, (size_t)c->grid.cells * sizeof(int2), c->stream));
     HIPCHK(c, hipMemsetAsync(c->ttable.p, 0, (size_t)c->grid.tiles * sizeof(int2), c->stream));
     HIPCHK(c, hipMemsetAsync(c->tileCtl.p, 0, SPH_QUEUE_SLOTS * sizeof(uint32_t), c->stream));
-    c->queueNext = 1;
+    c->queueNext = NB_CTL_QUEUE0;
+    c->havePlan = false;
     k_map_table<<<blocks_for(c->n, 256), 256, 0, c->stream>>>(c->sortedKeys, c->n, c->table.p,
                                                               c->ttable.p);
     k_tile_list<<<blocks_for(c->grid.tiles, 256), 256, 0, c->stream>>>(
@@ -1001,6 +1022,7 @@ int sph_reorder(SphCtx *c)
     HIPCHK(c, hipGetLastError());
     c->cur = nxt;
     c->ordered = true;
+    c->havePlan = false;
     c->haveDensity = c->haveForce = false;
     c->rhoInOrder = false;
     return SPH_OK;
@@ -1037,8 +1059,40 @@ static NbArgs neighbor_args(SphCtx *c, const SphParams *p, int cap)
         if (!(m.h <= c->grid.cellSize)) A.overread = 0;
     A.nmats = (int)c->mats.size();
     A.tileList = c->tileList.p;
-    A.tileCtl = c->tileCtl.p;
+    A.ctl = c->tileCtl.p;
+    A.blockList = c->blockList.p;
+    A.blockCap = (int)std::min<size_t>(c->blockList.cap, 1u << 30);
+    A.gcellList = c->gcellList.p;
+    A.gcellCap = (int)std::min<size_t>(c->gcellList.cap, 1u << 30);
+    A.pool = c->pool.p;
+    A.poolCap = (uint32_t)std::min<size_t>(c->pool.cap, 0xffffffffu);
     return A;
+}
+
+// The plan of this ordering (k_plan): once per step, used by the density and the force launch.
+static int ensure_plan(SphCtx *c, const SphParams *p)
+{
+    if (c->havePlan) return SPH_OK;
+    if (c->mats.size() > 65535) return fail(c, SPH_E_TOOLARGE, "more than 65535 distinct materials");
+    // sizes: a block has at least one target and a tile at most 32 blocks; a cell takes the
+    // global-memory path only if more than NB_CAP records lie in its 27 cells; a plan is at most
+    // 2.4 KB of halo table per block plus ~40 bytes per target and ~1 byte per record
+    const size_t N = (size_t)c->n, tiles = (size_t)c->grid.tiles;
+    const size_t tilesBound = std::min(tiles, N);
+    const size_t planWgsMax = 4 * (size_t)std::max(1, c->prop.multiProcessorCount);
+    int rc = ensure(c, c->blockList, std::min(tilesBound * 32, N) + 64 + planWgsMax * NB_LIST_PIECE);
+    if (!rc) rc = ensure(c, c->gcellList, (c->fallbackCap >= 0 ? N : (N + (size_t)c->nb) / 40) + 64);
+    if (!rc) rc = ensure(c, c->pool, (tilesBound * 6144 + N * 64) / 16 + 1024 + planWgsMax * NB_POOL_PIECE);
+    if (rc) return rc;
+    StageTimer t(c, SPH_T_TABLE);
+    NbArgs A = neighbor_args(c, p, NB_CAP);
+    // persistent workgroups (each takes its pieces of the pool and of the list): 4 per CU
+    const int planWgs = 4 * std::max(1, c->prop.multiProcessorCount);
+    const int grid = std::max(1, std::min((int)tilesBound, planWgs));
+    k_plan<<<grid, NB_PTHREADS, 0, c->stream>>>(A);
+    HIPCHK(c, hipGetLastError());
+    c->havePlan = true;
+    return SPH_OK;
 }
 
 // launches k_neighbors<FORCE,COUNT> as persistent workgroups: as many as the chip holds at once
@@ -1055,12 +1109,13 @@ template <bool FORCE, bool COUNT> static int launch_neighbors(SphCtx *c, NbArgs 
     }
     // every launch takes a fresh (zero) queue slot; they are all cleared with the tile table, so
     // there is no per-launch memset (a 4-byte hipMemsetAsync costs 20 us on the device)
-    if (c->queueNext >= SPH_QUEUE_SLOTS) {
-        HIPCHK(c, hipMemsetAsync(c->tileCtl.p + 1, 0, (SPH_QUEUE_SLOTS - 1) * sizeof(uint32_t),
-                                 c->stream));
-        c->queueNext = 1;
+    if (c->queueNext + 2 > SPH_QUEUE_SLOTS) {
+        HIPCHK(c, hipMemsetAsync(c->tileCtl.p + NB_CTL_QUEUE0, 0,
+                                 (SPH_QUEUE_SLOTS - NB_CTL_QUEUE0) * sizeof(uint32_t), c->stream));
+        c->queueNext = NB_CTL_QUEUE0;
     }
-    A.queue = c->queueNext++;
+    A.queue = c->queueNext;
+    c->queueNext += 2; // blocks, cells of the global-memory path
     k_neighbors<FORCE, COUNT><<<std::min(grid, std::max(c->grid.tiles, 1)), threads, 0, c->stream>>>(A);
     HIPCHK(c, hipGetLastError());
     return SPH_OK;
@@ -1074,8 +1129,9 @@ int sph_compute_density_and_pressure(SphCtx *c, const SphParams *p)
     if (!c->ordered) return fail(c, SPH_E_INVALID, "density before sph_reorder");
     rc = ensure_debug(c);
     if (rc) return rc;
+    if ((rc = ensure_plan(c, p))) return rc;
     StageTimer t(c, SPH_T_DENSITY);
-    NbArgs A = neighbor_args(c, p, NB_DCAP);
+    NbArgs A = neighbor_args(c, p, NB_CAP);
     if (c->debug & SPH_DEBUG_COUNTS) {
         A.counts = c->dcount.p;
         rc = launch_neighbors<false, true>(c, A);
@@ -1093,8 +1149,9 @@ int sph_compute_force(SphCtx *c, const SphParams *p)
     int rc = check_params(c, p);
     if (rc) return rc;
     if (!c->haveDensity) return fail(c, SPH_E_INVALID, "force before density");
+    if ((rc = ensure_plan(c, p))) return rc;
     StageTimer t(c, SPH_T_FORCE);
-    NbArgs A = neighbor_args(c, p, NB_FCAP);
+    NbArgs A = neighbor_args(c, p, NB_CAP);
     if (c->debug & SPH_DEBUG_COUNTS) {
         A.counts = c->fcount.p;
         rc = launch_neighbors<true, true>(c, A);

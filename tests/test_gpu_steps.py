@@ -34,8 +34,9 @@ def test_resident_steps_match_oracle(ctx, oracle, nsteps):
     ctx.step_resident(p, nsteps)
     gpos, gvel = ctx.download()
     opos, ovel, oboxes = oracle_steps(oracle, sc, nsteps)
-    # chaotic growth of rounding differences over 10 steps: 1e-5 at one step, 1e-4 at ten
-    rtol = 1e-5 if nsteps == 1 else 1e-4
+    # 1e-5 of the largest magnitude at one step and at ten (measured 4e-7 / 3e-6 at ten steps,
+    # below the oracle's own +1 ulp sensitivity: profiles/r2_divergence_demo.txt)
+    rtol = 1e-5
     assert_close(gpos, opos, rtol=rtol, what="position")
     assert_close(gvel, ovel, rtol=rtol, what="velocity")
     assert_close(ctx.get_colliders(), oboxes, rtol=rtol, what="bodies")
@@ -438,23 +439,36 @@ def test_golden_trajectory_1_10_100(ctx):
     """positions / velocities of the shipped scene after 1, 10 and 100 steps against the committed
     oracle trajectory.  Step 1: positions 1e-5 element by element (floor: 1 % of h); velocities
     1e-5 of the largest speed (after one step from rest every velocity is F/rho dt, a sum of pair
-    terms of that size which cancel; there is no smaller scale to be relative to).  Later steps: WCSPH with k = 512 amplifies a
-    1e-7 rounding difference by roughly x3 per step for the first steps and saturates (measured
-    curve: profiles/r2_divergence_demo.txt); the bars are the measured error times a margin, in
-    the norm of assert_close (relative to the largest magnitude)."""
+    terms of that size which cancel; there is no smaller scale to be relative to).  Step 10: 1e-5
+    of the largest magnitude.  WCSPH with k = 512 is chaotic: the ORACLE run again from positions
+    moved by one ulp is 7e-7 / 6e-6 (position / velocity, max norm) away from itself after 10 steps,
+    2e-4 / 7e-3 after 50 and 0.14 / 0.5 after 100, when single particles have swapped places
+    (measured curve: profiles/r2_divergence_demo.txt, tools/divergence.py).  At step 100 a
+    per-particle bar is therefore meaningless; what is compared is the median error (oracle floor
+    6.9e-4 of the largest coordinate, bar 1e-2) and bulk quantities: centre of mass and mean
+    speed."""
     t = np.load(os.path.join(GOLD, "demo_traj.npz"))
     sc = scene.demo_scene()
     p = load_scene(ctx, sc, debug=0, colliders=True)
     done = 0
-    for step, rtol in ((1, 1e-5), (10, 1e-4), (100, 5e-2)):
+    for step in (1, 10, 100):
         ctx.step_resident(p, step - done)
         done = step
         pos, vel = ctx.download()
-        if step == 1:
-            assert_close_elementwise(pos, t["pos1"], floor=0.01, what="position, step 1")
-            assert_close(vel, t["vel1"], what="velocity, step 1")
-        else:
-            assert_close(pos, t[f"pos{step}"], rtol=rtol, what=f"position, step {step}")
-            if step == 10:
-                assert_close(vel, t["vel10"], rtol=rtol, what="velocity, step 10")
+        wpos, wvel = t[f"pos{step}"], t[f"vel{step}"]
         assert np.isfinite(pos).all() and np.isfinite(vel).all()
+        if step == 1:
+            assert_close_elementwise(pos, wpos, floor=0.01, what="position, step 1")
+            assert_close(vel, wvel, what="velocity, step 1")
+        elif step == 10:
+            assert_close(pos, wpos, rtol=1e-5, what="position, step 10")
+            assert_close(vel, wvel, rtol=1e-5, what="velocity, step 10")
+        else:
+            scale = float(np.abs(wpos).max())
+            err = np.abs(pos.astype(np.float64) - wpos)
+            assert np.median(err) <= 1e-2 * scale, ("median position error, step 100", np.median(err))
+            com, wcom = pos.mean(axis=0, dtype=np.float64), wpos.mean(axis=0, dtype=np.float64)
+            assert np.abs(com - wcom).max() <= 2e-3 * scale, ("centre of mass, step 100", com, wcom)
+            sp = np.linalg.norm(vel.astype(np.float64), axis=1).mean()
+            wsp = np.linalg.norm(wvel.astype(np.float64), axis=1).mean()
+            assert abs(sp - wsp) <= 0.05 * wsp, ("mean speed, step 100", sp, wsp)
