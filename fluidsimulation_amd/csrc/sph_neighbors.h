@@ -95,8 +95,9 @@ struct UnitDesc {
     int gi0;     // global (sorted) index of the first target
     int self;    // LDS record index of the first target
     int slotA;   // slot-table index of list A
-    int slotB;   // slot-table index of list B
-    int pad0, pad1;
+    int slotB;   // slot-table index of list B (= slotA + slots of list A)
+    int maskw;   // first hit-mask word of the unit in the block's mask area
+    int pad1;
 };
 // block list entry: x = plan offset in the pool (16-byte units), y = tile,
 // z = halo cells | units << 8 | block origin (tile-local) x << 16 | y << 20 | z << 24,
@@ -120,7 +121,7 @@ struct PlanShared {
     int hmap[NB_HCELLS];      // block halo cell -> tile halo cell
     int spref[NB_HCELLS + 1]; // LDS record index of the block halo cell's records
     int2 cellf[SPH_TCELLS];   // per block cell: halo index in the tile, halo index in the block
-    int4 cslot[SPH_TCELLS];   // per block cell: slices, first slot (list A), first slot past the range
+    int4 cslot[SPH_TCELLS];   // per block cell: slices, first slot, first slot past the range, slots of list A
     int2 cwin[SPH_TCELLS][9]; // per cell and window: x = full slots | rest << 16 | tail in list A << 24,
                               //                      y = offset in list A | index in list B << 16
     int scan[4 * NB_MAXWAVES];
@@ -330,11 +331,14 @@ __device__ __forceinline__ void density_pair(const DensityTarget &t, const float
         acc = __builtin_fmaf(w * w, w, acc);
     } else {
         const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        const float w =
-            __builtin_amdgcn_fmed3f(__builtin_fmaf(d2, t.negInvH2, 1.0f), 0.f, 1.0f); // w / h2
+        // w / h2 = clamp(1 - d2/h2); the same fma without the clamp gives the MISS bit (its sign)
+        // for the force pass: hits = hits << 1 | miss, the newest slot in bit 0.  Both are
+        // full-rate instructions (a compare writing VCC and an add-with-carry cost 1.7x as much)
+        const float u = __builtin_fmaf(d2, t.negInvH2, 1.0f);
+        float w;
+        asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(w) : "v"(d2), "v"(t.negInvH2));
         acc = __builtin_fmaf(w * w, w, acc);
-        // hit mask for the force pass: hits = 2 hits + (w > 0), the newest slot in bit 0
-        asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(w) : "vcc");
+        hits = __builtin_amdgcn_alignbit(hits, __builtin_bit_cast(uint32_t, u), 31);
     }
 }
 
@@ -390,7 +394,7 @@ template <bool COUNT> struct Pass<false, COUNT> {
     DensityTarget t;
     float acc = 0.f;
     int cnt = 0;
-    uint32_t hits = 0; // one bit per slot walked since the last flush (production variant)
+    uint32_t hits = 0; // miss bit of the last 32 slots walked, newest in bit 0 (production variant)
     __device__ __forceinline__ void pair(const float4 &cp, const float4 &, bool)
     {
         density_pair<COUNT>(t, cp, acc, cnt, hits);
@@ -552,7 +556,7 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
 
     // 1. sizes: records per halo cell; targets, parts, slices and the slots of the nine windows
     int v4[4] = {0, 0, 0, 0}; // records, targets, units, slots
-    int P = 0, per = 0, S = 0, myf = 0, nA = 0, nB = 0;
+    int P = 0, per = 0, S = 0, myf = 0, nA = 0, nB = 0, mw = 0;
     int2 wd[9];
     if (tid < nh) {
         const int hx = tid % hxN, hy = (tid / hxN) % hyN, hz = tid / (hxN * hyN);
@@ -596,14 +600,17 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
                 nB += tailB;
             }
             v4[3] = (nA + nB + 3) & ~3;
-            v4[2] = P;
+            // units | hit-mask words (one word per 32 slots, lane and unit) << 12; the clamps only
+            // act on cells that make the block fail the checks below
+            mw = (nA + nB + 31) >> 5;
+            v4[2] = min(P, NB_MAXUNITS + 1) | (min(P * mw, 4095) << 12);
         }
     }
     int e4[4], t4[4];
     NB_STAMP(1);
     block_scan4(sh.scan, v4, e4, t4);
     NB_STAMP(2);
-    const int total = t4[0], ttotal = t4[1], nunits = t4[2], nslots = t4[3];
+    const int total = t4[0], ttotal = t4[1], nunits = t4[2] & 0xfff, nwords = t4[2] >> 12, nslots = t4[3];
     if (total > cap || ttotal > NB_TCAP || nunits > NB_MAXUNITS || nslots > NB_SLOTCAP) return false;
     if (ttotal == 0) return true;
     if (tid == 0) {
@@ -611,7 +618,8 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
         // workgroup takes from the device-wide counters NB_POOL_PIECE / NB_LIST_PIECE at a time:
         // one word serves only ~88 returning atomics per microsecond, one atomic per block would
         // cost most of a millisecond per step.
-        const uint32_t units16 = (uint32_t)(nh * 16 + nunits * 32 + nslots * 4) >> 4;
+        // plan, then the hit masks (64 lanes x 4 bytes per word)
+        const uint32_t units16 = ((uint32_t)(nh * 16 + nunits * 32 + nslots * 4) >> 4) + (uint32_t)nwords * 16;
         if (sh.poolAt + units16 > sh.poolEnd) {
             sh.poolAt = atomicAdd(&A.ctl[NB_CTL_POOL], (uint32_t)NB_POOL_PIECE);
             sh.poolEnd = sh.poolAt + NB_POOL_PIECE;
@@ -631,7 +639,7 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
     if (tid < nh) sh.spref[tid] = e4[0];
     if (tid == nh) sh.spref[nh] = total;
     if (tid < ncells && v4[1] > 0) {
-        sh.cslot[tid] = make_int4(S, e4[3], e4[3] + v4[3], 0);
+        sh.cslot[tid] = make_int4(S, e4[3], e4[3] + v4[3], nA);
 #pragma unroll
         for (int wi = 0; wi < 9; wi++) sh.cwin[tid][wi] = wd[wi];
     }
@@ -658,13 +666,14 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
                 u.gi0 = cstart + t0;
                 u.self = clds + t0;
                 u.slotA = e4[3];
-                u.slotB = e4[3] + v4[3] - nB;
-                u.pad0 = u.pad1 = 0;
-                unitG[e4[2] + part] = u;
+                u.slotB = e4[3] + nA;
+                u.maskw = (e4[2] >> 12) + part * mw;
+                u.pad1 = 0;
+                unitG[(e4[2] & 0xfff) + part] = u;
             }
         }
         // one task per (cell, window): its slots of list A from the front of the cell's range,
-        // its tail slot of list B (if any) from the back
+        // its tail slot of list B (if any) behind them
         for (int t = tid; t < ncells * 9; t += NT) {
             const int c = t / 9, wi = t - c * 9;
             const int4 cs = sh.cslot[c];
@@ -680,7 +689,7 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
             if (rem) {
                 const uint32_t tail = (uint32_t)((ws + nfull * Sc) * 16);
                 if (tailA) dst[nfull] = tail;
-                else slotG[cs.z - 1 - bidx] = tail | ((uint32_t)rem << 16);
+                else slotG[cs.y + cs.w + bidx] = tail | ((uint32_t)rem << 16);
             }
         }
         if (tid == 0)
@@ -767,6 +776,8 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
     const int total = hdr.w & 0x7ff, ttotal = (hdr.w >> 11) & 0x1ff, nslots = (hdr.w >> 20) & 0xfff;
     const int oUnits = nh * 16, oSlots = oUnits + nunits * 32, planBytes = oSlots + nslots * 4;
     (void)ttotal;
+    (void)total;
+    uint32_t *maskBlk = (uint32_t *)(A.pool + hdr.x + (planBytes >> 4)); // behind the plan
 
     NB_STAMP0();
     // 1. the plan: one linear LDS-DMA copy
@@ -912,56 +923,95 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
             ps.t.h2 = mt.z;
         }
         constexpr int G = FORCE ? NB_FG : NB_DG; // slots per iteration
-        // list A: lane reads entry + 16 * slice, nothing else per slot
-        const char *sp = slots + ud.slotA * 4;
-        int k = 0;
-        for (; k + G <= nA; k += G, sp += 4 * G) {
-            uint32_t e[G];
-            if constexpr (G == 4) {
-                const uint4 q = *(const uint4 *)sp;
-                e[0] = q.x; e[1] = q.y; e[2] = q.z; e[3] = q.w;
-            } else if constexpr (G == 2) {
-                const uint2 q = *(const uint2 *)sp;
-                e[0] = q.x; e[1] = q.y;
-            } else {
-#pragma unroll
-                for (int q = 0; q < G; q++) e[q] = ((const uint32_t *)sp)[q];
+        // hit masks of the unit: one word per 32 slots (list A, then list B) and lane
+        uint32_t *maskU = maskBlk + (size_t)ud.maskw * 64 + lane;
+        if (FORCE && !COUNT && A.useMasks) {
+            // Force pass over the hits the density pass found: every lane walks the set bits of
+            // its own words (bit i of word j = slot 32 j + i of the unit); lanes that have run
+            // out of hits are switched off, the wave goes on until its longest list ends.  A
+            // candidate the density pass left out is farther than h: its force terms are 0.
+            const int nwords = (nA + nB + 31) >> 5;
+            uint32_t m = __builtin_bitreverse32(maskU[0]);
+            const char *sbase = slots + ud.slotA * 4;
+            for (int j = 0; j < nwords; j++, sbase += 128) {
+                uint32_t mnext = 0;
+                if (j + 1 < nwords) mnext = maskU[(j + 1) * 64];
+                while (m) {
+                    const int bit = __builtin_ctz(m);
+                    m &= m - 1;
+                    const int off = (int)*(const uint16_t *)(sbase + bit * 4) + slice16;
+                    const float4 cp = *(const float4 *)(baseP + off);
+                    const float4 cv = *(const float4 *)(baseV + off);
+                    keep_b128(cp);
+                    keep_b128x(cv);
+                    ps.pair(cp, cv, true);
+                }
+                m = __builtin_bitreverse32(mnext);
             }
-            float4 cp[G], cv[G];
-            int off[G];
+        } else {
+            int g = 0; // slots walked (wave-uniform)
+            // stores the miss bits of the last nbits slots as a word of hit bits, slot 32 j + i
+            // in bit 31 - i (the force pass reverses the word)
+            auto flush = [&](int nbits) {
+                if (!FORCE && !COUNT) maskU[((g - 1) >> 5) * 64] = (~ps.hits) << (32 - nbits);
+            };
+            // list A: lane reads entry + 16 * slice, nothing else per slot
+            const char *sp = slots + ud.slotA * 4;
+            int k = 0;
+            for (; k + G <= nA; k += G, sp += 4 * G) {
+                uint32_t e[G];
+                if constexpr (G == 4) {
+                    const uint4 q = *(const uint4 *)sp;
+                    e[0] = q.x; e[1] = q.y; e[2] = q.z; e[3] = q.w;
+                } else if constexpr (G == 2) {
+                    const uint2 q = *(const uint2 *)sp;
+                    e[0] = q.x; e[1] = q.y;
+                } else {
 #pragma unroll
-            for (int q = 0; q < G; q++) {
-                off[q] = (int)e[q] + slice16;
-                cp[q] = *(const float4 *)(baseP + off[q]);
-                if (FORCE) cv[q] = *(const float4 *)(baseV + off[q]);
-            }
+                    for (int q = 0; q < G; q++) e[q] = ((const uint32_t *)sp)[q];
+                }
+                float4 cp[G], cv[G];
+                int off[G];
 #pragma unroll
-            for (int q = 0; q < G; q++) {
-                keep_b128(cp[q]);
-                if (FORCE) keep_b128x(cv[q]);
-                ps.pair(cp[q], cv[q], off[q] != self16);
+                for (int q = 0; q < G; q++) {
+                    off[q] = (int)e[q] + slice16;
+                    cp[q] = *(const float4 *)(baseP + off[q]);
+                    if (FORCE) cv[q] = *(const float4 *)(baseV + off[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < G; q++) {
+                    keep_b128(cp[q]);
+                    if (FORCE) keep_b128x(cv[q]);
+                    ps.pair(cp[q], cv[q], off[q] != self16);
+                }
+                g += G;
+                if ((g & 31) == 0) flush(32);
             }
-        }
-        for (; k < nA; k++, sp += 4) {
-            const int off = (int)*(const uint32_t *)sp + slice16;
-            const float4 cp = *(const float4 *)(baseP + off);
-            float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (FORCE) cv = *(const float4 *)(baseV + off);
-            keep_b128(cp);
-            if (FORCE) keep_b128x(cv);
-            ps.pair(cp, cv, off != self16);
-        }
-        // list B: slices at or past the entry's count read the FAR record
-        sp = slots + ud.slotB * 4;
-        for (int kb = 0; kb < nB; kb++, sp += 4) {
-            const uint32_t e = *(const uint32_t *)sp;
-            const int off = slice < (int)(e >> 16) ? (int)(e & 0xffffu) + slice16 : far16;
-            const float4 cp = *(const float4 *)(baseP + off);
-            float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (FORCE) cv = *(const float4 *)(baseV + off);
-            keep_b128(cp);
-            if (FORCE) keep_b128x(cv);
-            ps.pair(cp, cv, off != self16);
+            for (; k < nA; k++, sp += 4) {
+                const int off = (int)*(const uint32_t *)sp + slice16;
+                const float4 cp = *(const float4 *)(baseP + off);
+                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (FORCE) cv = *(const float4 *)(baseV + off);
+                keep_b128(cp);
+                if (FORCE) keep_b128x(cv);
+                ps.pair(cp, cv, off != self16);
+                g++;
+                if ((g & 31) == 0) flush(32);
+            }
+            // list B (right behind list A): slices at or past the entry's count read the FAR record
+            for (int kb = 0; kb < nB; kb++, sp += 4) {
+                const uint32_t e = *(const uint32_t *)sp;
+                const int off = slice < (int)(e >> 16) ? (int)(e & 0xffffu) + slice16 : far16;
+                const float4 cp = *(const float4 *)(baseP + off);
+                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (FORCE) cv = *(const float4 *)(baseV + off);
+                keep_b128(cp);
+                if (FORCE) keep_b128x(cv);
+                ps.pair(cp, cv, off != self16);
+                g++;
+                if ((g & 31) == 0) flush(32);
+            }
+            if (g & 31) flush(g & 31);
         }
         ps.finish(A, S2, slice, writer, ti, fc4);
     }

@@ -123,6 +123,7 @@ struct SphCtx {
     DevBuf<int2> gcellList;
     DevBuf<uint4> pool;
     bool havePlan = false;
+    bool haveMasks = false; // the production density pass has run on this plan
     int fallbackCap = -1; // debug: LDS record cap override for the neighbour kernels
 
     // boundary
@@ -725,7 +726,7 @@ int sph_set_debug(SphCtx *c, int32_t flags)
     if (!c) return SPH_E_INVALID;
     c->debug = flags;
     c->fallbackCap = (flags & SPH_DEBUG_NO_LDS_TILE) ? 0 : -1;
-    c->havePlan = false;
+    c->havePlan = c->haveMasks = false;
     return SPH_OK;
 }
 
@@ -997,7 +998,7 @@ int sph_map_table(SphCtx *c)
     HIPCHK(c, hipMemsetAsync(c->ttable.p, 0, (size_t)c->grid.tiles * sizeof(int2), c->stream));
     HIPCHK(c, hipMemsetAsync(c->tileCtl.p, 0, SPH_QUEUE_SLOTS * sizeof(uint32_t), c->stream));
     c->queueNext = NB_CTL_QUEUE0;
-    c->havePlan = false;
+    c->havePlan = c->haveMasks = false;
     k_map_table<<<blocks_for(c->n, 256), 256, 0, c->stream>>>(c->sortedKeys, c->n, c->table.p,
                                                               c->ttable.p);
     k_tile_list<<<blocks_for(c->grid.tiles, 256), 256, 0, c->stream>>>(
@@ -1022,7 +1023,7 @@ int sph_reorder(SphCtx *c)
     HIPCHK(c, hipGetLastError());
     c->cur = nxt;
     c->ordered = true;
-    c->havePlan = false;
+    c->havePlan = c->haveMasks = false;
     c->haveDensity = c->haveForce = false;
     c->rhoInOrder = false;
     return SPH_OK;
@@ -1076,13 +1077,14 @@ static int ensure_plan(SphCtx *c, const SphParams *p)
     if (c->mats.size() > 65535) return fail(c, SPH_E_TOOLARGE, "more than 65535 distinct materials");
     // sizes: a block has at least one target and a tile at most 32 blocks; a cell takes the
     // global-memory path only if more than NB_CAP records lie in its 27 cells; a plan is at most
-    // 2.4 KB of halo table per block plus ~40 bytes per target and ~1 byte per record
+    // 2.4 KB of halo table per block plus ~40 bytes per target and ~1 byte per record; the hit
+    // masks take 32 bytes per target when a cell's targets fill a wave, up to ~4x that in sparse cells
     const size_t N = (size_t)c->n, tiles = (size_t)c->grid.tiles;
     const size_t tilesBound = std::min(tiles, N);
     const size_t planWgsMax = 4 * (size_t)std::max(1, c->prop.multiProcessorCount);
     int rc = ensure(c, c->blockList, std::min(tilesBound * 32, N) + 64 + planWgsMax * NB_LIST_PIECE);
     if (!rc) rc = ensure(c, c->gcellList, (c->fallbackCap >= 0 ? N : (N + (size_t)c->nb) / 40) + 64);
-    if (!rc) rc = ensure(c, c->pool, (tilesBound * 6144 + N * 64) / 16 + 1024 + planWgsMax * NB_POOL_PIECE);
+    if (!rc) rc = ensure(c, c->pool, (tilesBound * 6144 + N * 192) / 16 + 1024 + planWgsMax * NB_POOL_PIECE);
     if (rc) return rc;
     StageTimer t(c, SPH_T_TABLE);
     NbArgs A = neighbor_args(c, p, NB_CAP);
@@ -1137,6 +1139,7 @@ int sph_compute_density_and_pressure(SphCtx *c, const SphParams *p)
         rc = launch_neighbors<false, true>(c, A);
     } else {
         rc = launch_neighbors<false, false>(c, A);
+        if (!rc) c->haveMasks = true;
     }
     if (rc) return rc;
     c->haveDensity = true;
@@ -1156,6 +1159,7 @@ int sph_compute_force(SphCtx *c, const SphParams *p)
         A.counts = c->fcount.p;
         rc = launch_neighbors<true, true>(c, A);
     } else {
+        A.useMasks = c->haveMasks ? 1 : 0;
         rc = launch_neighbors<true, false>(c, A);
     }
     if (rc) return rc;
