@@ -53,7 +53,7 @@
 #define NB_HY (SPH_TY + 2)
 #define NB_HZ (SPH_TZ + 2)
 #define NB_HCELLS (NB_HX * NB_HY * NB_HZ) // 144
-#define NB_PTHREADS 256 // workgroup size of the plan kernel
+#define NB_PTHREADS 64 // workgroup size of the plan kernel: one wave, no workgroup barriers
 #ifndef NB_DTHREADS
 #define NB_DTHREADS 256 // workgroup size of the density kernel
 #endif
@@ -76,6 +76,7 @@
 #define NB_MTAB 64       // materials whose loop constants are cached in LDS
 #define NB_POOL_PIECE 8192 // 16-byte units of plan pool a plan workgroup takes at a time (128 KB)
 #define NB_LIST_PIECE 16   // block-list entries it takes at a time
+#define NB_PLAN_WGS_PER_CU 16 // persistent plan workgroups (single waves) per CU
 #ifndef NB_CHUNK
 #define NB_CHUNK 4 // blocks per work-queue request
 #endif
@@ -115,17 +116,14 @@ struct HaloTab {
     int bc[NB_HCELLS]; // boundary count
 };
 
-// LDS of the plan kernel
+// LDS of the plan kernel (one wave per workgroup, one tile at a time)
 struct PlanShared {
     HaloTab h;
-    int hmap[NB_HCELLS];      // block halo cell -> tile halo cell
     int spref[NB_HCELLS + 1]; // LDS record index of the block halo cell's records
     int2 cellf[SPH_TCELLS];   // per block cell: halo index in the tile, halo index in the block
     int4 cslot[SPH_TCELLS];   // per block cell: slices, first slot, first slot past the range, slots of list A
     int2 cwin[SPH_TCELLS][9]; // per cell and window: x = full slots | rest << 16 | tail in list A << 24,
                               //                      y = offset in list A | index in list B << 16
-    int scan[4 * NB_MAXWAVES];
-    int alloc[2];             // plan offset, block index of the block being planned
     uint32_t poolAt, poolEnd; // this workgroup's current piece of the pool (16-byte units)
     uint32_t listAt, listEnd; // this workgroup's current run of block-list entries
 };
@@ -194,6 +192,16 @@ __device__ __forceinline__ int row16_incl_scan(int v)
     return v;
 }
 
+// inclusive scan over the 64 lanes of the wave: rows of 16, then the row totals (row_bcast:15 into
+// rows 1 and 3, row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v = row16_incl_scan(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // Sum over the S consecutive lanes of a slice group, valid in the group's first lane (slice 0).
 // Groups of 2/4/8/16 lanes never straddle a DPP row of 16, larger or odd groups go through
 // ds_bpermute.  The order of the additions depends only on S.
@@ -241,59 +249,23 @@ static __device__ unsigned long long g_stamps[32];
 #define NB_STAMP(i)
 #endif
 
-// exclusive scan of four values per thread over the workgroup; t = the four totals
-__device__ __forceinline__ void block_scan4(int *scan, const int (&v)[4], int (&e)[4], int (&t)[4])
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int i4[4] = {v[0], v[1], v[2], v[3]};
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = __shfl_up(i4[k], d, 64);
-            if (lane >= d) i4[k] += x;
-        }
-    }
-    __syncthreads(); // previous users of scan[] are done
-    if (lane == 63)
-#pragma unroll
-        for (int k = 0; k < 4; k++) scan[4 * w + k] = i4[k];
-    __syncthreads();
-    int base[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 4; k++) t[k] = 0;
-#pragma unroll
-    for (int i = 0; i < NB_MAXWAVES; i++) {
-        if (i >= nw) break;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = scan[4 * i + k];
-            if (i < w) base[k] += x;
-            t[k] += x;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) e[k] = base[k] + i4[k] - v[k];
-}
-
 // table look-ups for the 6x6x4 halo of the tile
 __device__ __forceinline__ void tile_lookup(HaloTab &h, int tile, const NbArgs &A)
 {
     const GridDesc &g = A.g;
-    const int tid = threadIdx.x;
-    if (tid < NB_HCELLS) {
-        const int tx = tile % g.ntx, t2 = tile / g.ntx, ty = t2 % g.nty, tz = t2 / g.nty;
-        const int hx = tid % NB_HX, hy = (tid / NB_HX) % NB_HY, hz = tid / (NB_HX * NB_HY);
+    const int tx = tile % g.ntx, t2 = tile / g.ntx, ty = t2 % g.nty, tz = t2 / g.nty;
+    for (int c = threadIdx.x; c < NB_HCELLS; c += blockDim.x) {
+        const int hx = c % NB_HX, hy = (c / NB_HX) % NB_HY, hz = c / (NB_HX * NB_HY);
         const int x = wrapi(tx * SPH_TX + hx - 1, g.gx), y = wrapi(ty * SPH_TY + hy - 1, g.gy),
                   z = wrapi(tz * SPH_TZ + hz - 1, g.gz);
         const uint32_t k = tiled_key(x, y, z, g);
         const int2 f = A.table[k];
         int2 b = make_int2(0, 0);
         if (A.btable) b = A.btable[k];
-        h.fs[tid] = f.x;
-        h.fc[tid] = f.y - f.x;
-        h.bs[tid] = b.x;
-        h.bc[tid] = b.y - b.x;
+        h.fs[c] = f.x;
+        h.fc[c] = f.y - f.x;
+        h.bs[c] = b.x;
+        h.bc[c] = b.y - b.x;
     }
     __syncthreads();
 }
@@ -541,35 +513,48 @@ __device__ void process_cell_global(const HaloTab &sh, const NbArgs &A, int lx, 
 // ------------------------------------------------------------------------------------------
 // PLAN KERNEL
 
-// the plan of one block (bx0.., sx x sy x sz cells, tile-local).  Returns false, having done
-// nothing, when the block's halo, targets, units or slots do not fit.  hinfo.z = fluid count |
-// boundary count << 16.
+// The plan of one block (bx0.., sx x sy x sz cells, tile-local), by one wave.  Returns false,
+// having done nothing, when the block's halo, targets, units or slots do not fit.  hinfo.z = fluid
+// count | boundary count << 16.
 template <int sx, int sy, int sz>
 __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int tile, int bx0, int by0,
                                            int bz0)
 {
-    constexpr int NT = NB_PTHREADS;
     constexpr int hxN = sx + 2, hyN = sy + 2, nh = hxN * hyN * (sz + 2), ncells = sx * sy * sz;
-    const int tid = threadIdx.x;
-    const int cap = A.cap;
-    NB_STAMP0();
+    static_assert(nh <= 3 * 64 && ncells <= 64, "three halo cells and one block cell per lane");
+    const int lane = threadIdx.x;
 
-    // 1. sizes: records per halo cell; targets, parts, slices and the slots of the nine windows
-    int v4[4] = {0, 0, 0, 0}; // records, targets, units, slots
-    int P = 0, per = 0, S = 0, myf = 0, nA = 0, nB = 0, mw = 0;
-    int2 wd[9];
-    if (tid < nh) {
-        const int hx = tid % hxN, hy = (tid / hxN) % hyN, hz = tid / (hxN * hyN);
-        myf = tile_halo_index(bx0 + hx, by0 + hy, bz0 + hz);
-        sh.hmap[tid] = myf;
-        v4[0] = sh.h.fc[myf] + sh.h.bc[myf];
+    // 1. records per halo cell (lane l: cells 3l .. 3l+2) and their places in the image
+    int myf[3], rc[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int h = 3 * lane + i;
+        myf[i] = 0;
+        rc[i] = 0;
+        if (h < nh) {
+            const int hx = h % hxN, hy = (h / hxN) % hyN, hz = h / (hxN * hyN);
+            myf[i] = tile_halo_index(bx0 + hx, by0 + hy, bz0 + hz);
+            rc[i] = sh.h.fc[myf[i]] + sh.h.bc[myf[i]];
+        }
     }
-    if (tid < ncells) {
-        const int cx = tid % sx, cy = (tid / sx) % sy, cz = tid / (sx * sy);
-        const int f = tile_halo_index(bx0 + cx + 1, by0 + cy + 1, bz0 + cz + 1);
-        const int tcnt = sh.h.fc[f];
-        sh.cellf[tid] = make_int2(f, ((cz + 1) * hyN + (cy + 1)) * hxN + (cx + 1));
-        v4[1] = tcnt;
+    const int rsum = rc[0] + rc[1] + rc[2];
+    const int rincl = wave_incl_scan(rsum);
+    const int total = __builtin_amdgcn_readlane(rincl, 63);
+    if (total > A.cap) return false;
+    const int rex[3] = {rincl - rsum, rincl - rsum + rc[0], rincl - rsum + rc[0] + rc[1]};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        if (3 * lane + i < nh) sh.spref[3 * lane + i] = rex[i];
+    if (lane == 0) sh.spref[nh] = total;
+
+    // 2. per block cell: targets, parts, slices and the slots of the nine windows
+    int tcnt = 0, P = 0, per = 0, S = 0, nA = 0, nB = 0, mw = 0, uw = 0, nsl = 0, f = 0, fb = 0;
+    if (lane < ncells) {
+        const int cx = lane % sx, cy = (lane / sx) % sy, cz = lane / (sx * sy);
+        f = tile_halo_index(bx0 + cx + 1, by0 + cy + 1, bz0 + cz + 1);
+        fb = ((cz + 1) * hyN + (cy + 1)) * hxN + (cx + 1);
+        tcnt = sh.h.fc[f];
+        sh.cellf[lane] = make_int2(f, fb);
         if (tcnt > 0) {
             // at most 32 targets per unit (S >= 2), and at least 8 units per block
             P = max((tcnt + 31) >> 5, min(tcnt, (NB_MAXWAVES + ncells - 1) / ncells));
@@ -595,93 +580,92 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
                 const int nfull = div_small(len, S), rem = len - nfull * S;
                 const int tailA = (rem != 0 && A.overread && S - rem <= rest) ? 1 : 0;
                 const int tailB = (rem != 0 && !tailA) ? 1 : 0;
-                wd[wi] = make_int2(nfull | (rem << 16) | (tailA << 24), nA | (nB << 16));
+                sh.cwin[lane][wi] = make_int2(nfull | (rem << 16) | (tailA << 24), nA | (nB << 16));
                 nA += nfull + tailA;
                 nB += tailB;
             }
-            v4[3] = (nA + nB + 3) & ~3;
+            nsl = (nA + nB + 3) & ~3;
             // units | hit-mask words (one word per 32 slots, lane and unit) << 12; the clamps only
             // act on cells that make the block fail the checks below
             mw = (nA + nB + 31) >> 5;
-            v4[2] = min(P, NB_MAXUNITS + 1) | (min(P * mw, 4095) << 12);
+            uw = min(P, NB_MAXUNITS + 1) | (min(P * mw, 4095) << 12);
         }
     }
-    int e4[4], t4[4];
-    NB_STAMP(1);
-    block_scan4(sh.scan, v4, e4, t4);
-    NB_STAMP(2);
-    const int total = t4[0], ttotal = t4[1], nunits = t4[2] & 0xfff, nwords = t4[2] >> 12, nslots = t4[3];
-    if (total > cap || ttotal > NB_TCAP || nunits > NB_MAXUNITS || nslots > NB_SLOTCAP) return false;
+    const int tincl = wave_incl_scan(tcnt), uincl = wave_incl_scan(uw), sincl = wave_incl_scan(nsl);
+    const int ttotal = __builtin_amdgcn_readlane(tincl, 63), ut = __builtin_amdgcn_readlane(uincl, 63),
+              nslots = __builtin_amdgcn_readlane(sincl, 63);
+    const int nunits = ut & 0xfff, nwords = ut >> 12;
+    if (ttotal > NB_TCAP || nunits > NB_MAXUNITS || nslots > NB_SLOTCAP) return false;
     if (ttotal == 0) return true;
-    if (tid == 0) {
-        // Room for the plan and a place in the block list.  Both come out of pieces that the
-        // workgroup takes from the device-wide counters NB_POOL_PIECE / NB_LIST_PIECE at a time:
-        // one word serves only ~88 returning atomics per microsecond, one atomic per block would
-        // cost most of a millisecond per step.
-        // plan, then the hit masks (64 lanes x 4 bytes per word)
+    const int uex = uincl - uw, sex = sincl - nsl;
+
+    // Room for the plan (and, behind it, the hit masks: 64 lanes x 4 bytes per word) and a place
+    // in the block list.  Both come out of pieces that the workgroup takes from the device-wide
+    // counters: one word serves only ~88 returning atomics per microsecond, one atomic per block
+    // would cost most of a millisecond per step.
+    int off = 0, idx = 0;
+    if (lane == 0) {
         const uint32_t units16 = ((uint32_t)(nh * 16 + nunits * 32 + nslots * 4) >> 4) + (uint32_t)nwords * 16;
         if (sh.poolAt + units16 > sh.poolEnd) {
-            sh.poolAt = atomicAdd(&A.ctl[NB_CTL_POOL], (uint32_t)NB_POOL_PIECE);
-            sh.poolEnd = sh.poolAt + NB_POOL_PIECE;
+            const uint32_t piece = max(units16, (uint32_t)NB_POOL_PIECE);
+            sh.poolAt = atomicAdd(&A.ctl[NB_CTL_POOL], piece);
+            sh.poolEnd = sh.poolAt + piece;
         }
         if (sh.listAt == sh.listEnd) {
             sh.listAt = atomicAdd(&A.ctl[NB_CTL_BLOCKS], (uint32_t)NB_LIST_PIECE);
             sh.listEnd = sh.listAt + NB_LIST_PIECE;
         }
-        const uint32_t off = sh.poolAt, idx = sh.listAt;
-        const bool ok = off + units16 <= A.poolCap && idx < (uint32_t)A.blockCap;
+        const uint32_t o = sh.poolAt, i = sh.listAt;
+        const bool ok = o + units16 <= A.poolCap && i < (uint32_t)A.blockCap;
         if (!ok) atomicOr(&A.ctl[NB_CTL_ERROR], 1u);
         sh.poolAt += units16;
         sh.listAt += 1;
-        sh.alloc[0] = ok ? (int)off : -1;
-        sh.alloc[1] = (int)idx;
+        off = ok ? (int)o : -1;
+        idx = (int)i;
     }
-    if (tid < nh) sh.spref[tid] = e4[0];
-    if (tid == nh) sh.spref[nh] = total;
-    if (tid < ncells && v4[1] > 0) {
-        sh.cslot[tid] = make_int4(S, e4[3], e4[3] + v4[3], nA);
-#pragma unroll
-        for (int wi = 0; wi < 9; wi++) sh.cwin[tid][wi] = wd[wi];
-    }
-    __syncthreads();
-    NB_STAMP(3);
+    off = __builtin_amdgcn_readfirstlane(off);
+    idx = __builtin_amdgcn_readfirstlane(idx);
+    if (lane < ncells && tcnt > 0) sh.cslot[lane] = make_int4(S, sex, sex + nsl, nA);
+    wave_lds_fence();
 
-    // 2. the plan goes straight to global memory: hinfo | units | slots
-    const int off = sh.alloc[0];
+    // 3. the plan goes straight to global memory: hinfo | units | slots
     if (off >= 0) {
         int4 *hinfoG = (int4 *)(A.pool + off);
         UnitDesc *unitG = (UnitDesc *)(hinfoG + nh);
         uint32_t *slotG = (uint32_t *)(unitG + nunits);
-        if (tid < nh)
-            hinfoG[tid] = make_int4(e4[0], sh.h.fs[myf], sh.h.fc[myf] | (sh.h.bc[myf] << 16), sh.h.bs[myf]);
-        if (tid < ncells && v4[1] > 0) {
-            const int2 cf = sh.cellf[tid];
-            const int cstart = sh.h.fs[cf.x], clds = sh.spref[cf.y];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (3 * lane + i < nh)
+                hinfoG[3 * lane + i] = make_int4(rex[i], sh.h.fs[myf[i]],
+                                                 sh.h.fc[myf[i]] | (sh.h.bc[myf[i]] << 16), sh.h.bs[myf[i]]);
+        if (lane < ncells && tcnt > 0) {
+            const int cstart = sh.h.fs[f], clds = sh.spref[fb];
 #pragma nounroll
             for (int part = 0; part < P; part++) {
                 const int t0 = part * per;
                 UnitDesc u;
-                u.tS = min(per, v4[1] - t0) | (S << 8);
+                u.tS = min(per, tcnt - t0) | (S << 8);
                 u.nAB = nA | (nB << 16);
                 u.gi0 = cstart + t0;
                 u.self = clds + t0;
-                u.slotA = e4[3];
-                u.slotB = e4[3] + nA;
-                u.maskw = (e4[2] >> 12) + part * mw;
+                u.slotA = sex;
+                u.slotB = sex + nA;
+                u.maskw = (uex >> 12) + part * mw;
                 u.pad1 = 0;
-                unitG[(e4[2] & 0xfff) + part] = u;
+                unitG[(uex & 0xfff) + part] = u;
             }
         }
         // one task per (cell, window): its slots of list A from the front of the cell's range,
         // its tail slot of list B (if any) behind them
-        for (int t = tid; t < ncells * 9; t += NT) {
+        for (int t = lane; t < ncells * 9; t += NB_PTHREADS) {
             const int c = t / 9, wi = t - c * 9;
+            const int2 cf = sh.cellf[c];
+            if (sh.h.fc[cf.x] == 0) continue;
             const int4 cs = sh.cslot[c];
-            if (sh.h.fc[sh.cellf[c].x] == 0) continue;
             const int2 wdv = sh.cwin[c][wi];
             const int nfull = wdv.x & 0xffff, rem = (wdv.x >> 16) & 0xff, tailA = (wdv.x >> 24) & 1;
             const int aoff = wdv.y & 0xffff, bidx = wdv.y >> 16;
-            const int h0 = sh.cellf[c].y + ((wi / 3) - 1) * (hxN * hyN) + ((wi % 3) - 1) * hxN - 1;
+            const int h0 = cf.y + ((wi / 3) - 1) * (hxN * hyN) + ((wi % 3) - 1) * hxN - 1;
             const int ws = sh.spref[h0], Sc = cs.x;
             uint32_t *dst = slotG + cs.y + aoff;
 #pragma nounroll
@@ -692,28 +676,24 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
                 else slotG[cs.y + cs.w + bidx] = tail | ((uint32_t)rem << 16);
             }
         }
-        if (tid == 0)
-            A.blockList[sh.alloc[1]] =
+        if (lane == 0)
+            A.blockList[idx] =
                 make_int4(off, tile, nh | (nunits << 8) | (bx0 << 16) | (by0 << 20) | (bz0 << 24),
                           total | (ttotal << 11) | (nslots << 20));
     }
-    NB_STAMP(4);
-    __syncthreads(); // the LDS tables are reused by the next block
-    NB_STAMP(5);
+    wave_lds_fence(); // the LDS tables are reused by the next block
     return true;
 }
 
-// one workgroup per non-empty tile
-__global__ __launch_bounds__(NB_PTHREADS, 4) void k_plan(NbArgs A)
+// one wave per non-empty tile at a time
+__global__ __launch_bounds__(NB_PTHREADS) void k_plan(NbArgs A)
 {
     __shared__ PlanShared sh;
     if (threadIdx.x == 0) sh.poolAt = sh.poolEnd = sh.listAt = sh.listEnd = 0;
     const uint32_t ntiles = A.ctl[NB_CTL_TILES];
     for (uint32_t ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
         const int tile = (int)A.tileList[ti];
-        NB_STAMP0();
         tile_lookup(sh.h, tile, A);
-        NB_STAMP(0);
         // The largest block whose 27-cell halo fits the LDS image: the whole tile, then halves
         // (4x4x1, 4x2x1, 2x2x1) down to single cells, then the global-memory path.  The 32 cells
         // are numbered so that every block is an aligned run: n = z*16 + (y/2)*8 + (x/2)*4 +
@@ -749,8 +729,9 @@ __global__ __launch_bounds__(NB_PTHREADS, 4) void k_plan(NbArgs A)
         __syncthreads(); // sh.h is rewritten by the next tile
     }
     // the unused entries of this workgroup's last run of the block list: empty blocks
-    for (uint32_t i = sh.listAt + threadIdx.x; i < sh.listEnd; i += NB_PTHREADS)
-        if (i < (uint32_t)A.blockCap) A.blockList[i] = make_int4(0, 0, 0, 0);
+    if (threadIdx.x == 0)
+        for (uint32_t i = sh.listAt; i < sh.listEnd; i++)
+            if (i < (uint32_t)A.blockCap) A.blockList[i] = make_int4(0, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -776,7 +757,6 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
     const int total = hdr.w & 0x7ff, ttotal = (hdr.w >> 11) & 0x1ff, nslots = (hdr.w >> 20) & 0xfff;
     const int oUnits = nh * 16, oSlots = oUnits + nunits * 32, planBytes = oSlots + nslots * 4;
     (void)ttotal;
-    (void)total;
     uint32_t *maskBlk = (uint32_t *)(A.pool + hdr.x + (planBytes >> 4)); // behind the plan
 
     NB_STAMP0();
@@ -792,66 +772,34 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
     __syncthreads();
     NB_STAMP((FORCE ? 16 : 8) + 0);
 
-    // 2. the records of the halo, fluid then boundary per cell.  Eight lanes per cell, eight
-    // cells per wave-instruction; every lane knows its source and its place in the image from the
-    // cell's hinfo alone.  All loads of a wave are issued before the first is waited for.
+    // 2. the records of the halo, fluid then boundary per cell.  First every image slot gets the
+    // index of its source record, written into the slot itself (eight lanes per halo cell); then
+    // the waves copy the image in pieces of 64 records by LDS-DMA (global_load_lds_dwordx4 takes a
+    // source address per lane and writes 1 KiB of LDS from the M0 base: no VGPR staging).
     const int4 *hinfo = (const int4 *)sh.plan;
     const UnitDesc *units = (const UnitDesc *)(sh.plan + oUnits);
     float4 *recP = sh.recP, *recV = sh.recV;
     {
-        constexpr int NG = (NB_HCELLS / 8 + NB_WAVES - 1) / NB_WAVES; // cell groups per wave
-        static_assert(NG <= 5, "five named register sets below");
+        uint32_t *slot0 = (uint32_t *)recP;
         const int k = lane & 7;
-        int more = 0;
-        // (named variables, not arrays: the register allocator keeps arrays with predicated
-        // writes in scratch memory)
-#define NB_LOAD_GROUP(g, RP, RV, DST)                                                            \
-        float4 RP = make_float4(0.f, 0.f, 0.f, 0.f), RV = RP;                                    \
-        int DST = -1;                                                                            \
-        if (g < NG) {                                                                            \
-            const int c = (w + g * NB_WAVES) * 8 + (lane >> 3);                                  \
-            if (c < nh) {                                                                        \
-                const int4 hi = hinfo[c];                                                        \
-                const int fc = hi.z & 0xffff, cnt = fc + (hi.z >> 16);                           \
-                more |= cnt > 8;                                                                 \
-                if (k < cnt) {                                                                   \
-                    DST = hi.x + k;                                                              \
-                    if (k < fc) {                                                                \
-                        RP = A.posm[hi.y + k];                                                   \
-                        if (FORCE) RV = A.velq[hi.y + k];                                        \
-                    } else {                                                                     \
-                        RP = A.bposm[hi.w + (k - fc)]; /* boundary: v = 0, q = 0 */              \
-                    }                                                                            \
-                }                                                                                \
-            }                                                                                    \
+        for (int c = w * 8 + (lane >> 3); c < nh; c += NB_WAVES * 8) {
+            const int4 hi = hinfo[c];
+            const int fc = hi.z & 0xffff, cnt = fc + (hi.z >> 16);
+            for (int k2 = k; k2 < cnt; k2 += 8)
+                slot0[4 * (hi.x + k2)] =
+                    k2 < fc ? (uint32_t)(hi.y + k2) : 0x80000000u | (uint32_t)(hi.w + (k2 - fc));
         }
-#define NB_STORE_GROUP(RP, RV, DST)                                                              \
-        if (DST >= 0) {                                                                          \
-            recP[DST] = RP;                                                                      \
-            if (FORCE) recV[DST] = RV;                                                           \
-        }
-        NB_LOAD_GROUP(0, rp0, rv0, d0)
-        NB_LOAD_GROUP(1, rp1, rv1, d1)
-        NB_LOAD_GROUP(2, rp2, rv2, d2)
-        NB_LOAD_GROUP(3, rp3, rv3, d3)
-        NB_LOAD_GROUP(4, rp4, rv4, d4)
-        NB_STORE_GROUP(rp0, rv0, d0)
-        NB_STORE_GROUP(rp1, rv1, d1)
-        NB_STORE_GROUP(rp2, rv2, d2)
-        NB_STORE_GROUP(rp3, rv3, d3)
-        NB_STORE_GROUP(rp4, rv4, d4)
-#undef NB_LOAD_GROUP
-#undef NB_STORE_GROUP
-        if (__builtin_amdgcn_ballot_w64(more != 0)) { // cells with more than eight records
-            for (int g = 0; g < NG; g++) {
-                const int c = (w + g * NB_WAVES) * 8 + (lane >> 3);
-                if (c >= nh) continue;
-                const int4 hi = hinfo[c];
-                const int fc = hi.z & 0xffff, cnt = fc + (hi.z >> 16);
-                for (int k2 = k + 8; k2 < cnt; k2 += 8) {
-                    recP[hi.x + k2] = k2 < fc ? A.posm[hi.y + k2] : A.bposm[hi.w + (k2 - fc)];
-                    if (FORCE) recV[hi.x + k2] = k2 < fc ? A.velq[hi.y + k2] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+    }
+    __syncthreads();
+    for (int p0 = w * 64; p0 < total; p0 += NT) { // wave-uniform
+        if (p0 + lane < total) {
+            const uint32_t src = ((const uint32_t *)recP)[4 * (p0 + lane)];
+            const bool bnd = (src >> 31) != 0; // boundary: v = 0, q = 0
+            const float4 *gp = bnd ? A.bposm + (src & 0x7fffffffu) : A.posm + src;
+            __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(recP + p0), 16, 0, 0);
+            if (FORCE) {
+                const float4 *gv = bnd ? A.zeros : (const float4 *)A.velq + src;
+                __builtin_amdgcn_global_load_lds((gptr_t)gv, (lptr_t)(recV + p0), 16, 0, 0);
             }
         }
     }

@@ -1081,15 +1081,15 @@ static int ensure_plan(SphCtx *c, const SphParams *p)
     // masks take 32 bytes per target when a cell's targets fill a wave, up to ~4x that in sparse cells
     const size_t N = (size_t)c->n, tiles = (size_t)c->grid.tiles;
     const size_t tilesBound = std::min(tiles, N);
-    const size_t planWgsMax = 4 * (size_t)std::max(1, c->prop.multiProcessorCount);
+    const size_t planWgsMax = NB_PLAN_WGS_PER_CU * (size_t)std::max(1, c->prop.multiProcessorCount);
     int rc = ensure(c, c->blockList, std::min(tilesBound * 32, N) + 64 + planWgsMax * NB_LIST_PIECE);
     if (!rc) rc = ensure(c, c->gcellList, (c->fallbackCap >= 0 ? N : (N + (size_t)c->nb) / 40) + 64);
     if (!rc) rc = ensure(c, c->pool, (tilesBound * 6144 + N * 192) / 16 + 1024 + planWgsMax * NB_POOL_PIECE);
     if (rc) return rc;
     StageTimer t(c, SPH_T_TABLE);
     NbArgs A = neighbor_args(c, p, NB_CAP);
-    // persistent workgroups (each takes its pieces of the pool and of the list): 4 per CU
-    const int planWgs = 4 * std::max(1, c->prop.multiProcessorCount);
+    // persistent single-wave workgroups (each takes its pieces of the pool and of the list)
+    const int planWgs = NB_PLAN_WGS_PER_CU * std::max(1, c->prop.multiProcessorCount);
     const int grid = std::max(1, std::min((int)tilesBound, planWgs));
     k_plan<<<grid, NB_PTHREADS, 0, c->stream>>>(A);
     HIPCHK(c, hipGetLastError());
