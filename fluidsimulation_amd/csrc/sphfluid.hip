@@ -78,6 +78,9 @@ static std::mutex g_scratchLock;
 struct SphCtx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // second stream: the neighbour plan of a step runs beside the reorder pass (sph_step_resident)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t evTable = nullptr, evPlan = nullptr;
     hipDeviceProp_t prop;
     std::string err;
     int debug = 0;
@@ -207,7 +210,9 @@ struct StageTimer {
     SphCtx *c;
     EventPair ep;
     bool on;
-    StageTimer(SphCtx *ctx, int stage) : c(ctx), on(ctx->timing)
+    hipStream_t s;
+    StageTimer(SphCtx *ctx, int stage, hipStream_t stream = nullptr)
+        : c(ctx), on(ctx->timing), s(stream ? stream : ctx->stream)
     {
         if (!on) return;
         for (hipEvent_t *e : {&ep.a, &ep.b}) {
@@ -220,12 +225,12 @@ struct StageTimer {
             }
         }
         ep.stage = stage;
-        (void)hipEventRecord(ep.a, c->stream);
+        (void)hipEventRecord(ep.a, s);
     }
     ~StageTimer()
     {
         if (!on) return;
-        (void)hipEventRecord(ep.b, c->stream);
+        (void)hipEventRecord(ep.b, s);
         c->pending.push_back(ep);
     }
 };
@@ -254,6 +259,7 @@ void drain_timings(SphCtx *c)
 int collect_timings(SphCtx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
     for (const EventPair &ep : c->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
@@ -647,6 +653,13 @@ int sph_create(const SphConfig *cfg, SphCtx **out)
         delete c;
         return fail(nullptr, SPH_E_DEVICE, "hipStreamCreate failed");
     }
+    // optional: without them the plan simply runs on the main stream
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) c->stream2 = nullptr;
+    if (c->stream2 && (hipEventCreateWithFlags(&c->evTable, hipEventDisableTiming) != hipSuccess ||
+                       hipEventCreateWithFlags(&c->evPlan, hipEventDisableTiming) != hipSuccess)) {
+        (void)hipStreamDestroy(c->stream2);
+        c->stream2 = nullptr;
+    }
     if (dev < SPH_MAX_DEVICES) { // this device's copy of `scratch` (device `dev` is current)
         std::lock_guard<std::mutex> lk(g_scratchLock);
         if (!g_scratchPtr[dev]) {
@@ -707,6 +720,9 @@ int sph_destroy(SphCtx *c)
     }
     for (hipEvent_t e : c->freeEvents) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->evTable) (void)hipEventDestroy(c->evTable);
+    if (c->evPlan) (void)hipEventDestroy(c->evPlan);
     delete c;
     return SPH_OK;
 }
@@ -1023,7 +1039,7 @@ int sph_reorder(SphCtx *c)
     HIPCHK(c, hipGetLastError());
     c->cur = nxt;
     c->ordered = true;
-    c->havePlan = c->haveMasks = false;
+    c->haveMasks = false; // (the plan depends on the table only: it stays)
     c->haveDensity = c->haveForce = false;
     c->rhoInOrder = false;
     return SPH_OK;
@@ -1071,9 +1087,10 @@ static NbArgs neighbor_args(SphCtx *c, const SphParams *p, int cap)
 }
 
 // The plan of this ordering (k_plan): once per step, used by the density and the force launch.
-static int ensure_plan(SphCtx *c, const SphParams *p)
+static int ensure_plan(SphCtx *c, const SphParams *p, hipStream_t stream = nullptr)
 {
     if (c->havePlan) return SPH_OK;
+    if (!stream) stream = c->stream;
     if (c->mats.size() > 65535) return fail(c, SPH_E_TOOLARGE, "more than 65535 distinct materials");
     // sizes: a block has at least one target and a tile at most 32 blocks; a cell takes the
     // global-memory path only if more than NB_CAP records lie in its 27 cells; a plan is at most
@@ -1086,12 +1103,12 @@ static int ensure_plan(SphCtx *c, const SphParams *p)
     if (!rc) rc = ensure(c, c->gcellList, (c->fallbackCap >= 0 ? N : (N + (size_t)c->nb) / 40) + 64);
     if (!rc) rc = ensure(c, c->pool, (tilesBound * 6144 + N * 192) / 16 + 1024 + planWgsMax * NB_POOL_PIECE);
     if (rc) return rc;
-    StageTimer t(c, SPH_T_TABLE);
+    StageTimer t(c, SPH_T_PLAN, stream);
     NbArgs A = neighbor_args(c, p, NB_CAP);
     // persistent single-wave workgroups (each takes its pieces of the pool and of the list)
     const int planWgs = NB_PLAN_WGS_PER_CU * std::max(1, c->prop.multiProcessorCount);
     const int grid = std::max(1, std::min((int)tilesBound, planWgs));
-    k_plan<<<grid, NB_PTHREADS, 0, c->stream>>>(A);
+    k_plan<<<grid, NB_PTHREADS, 0, stream>>>(A);
     HIPCHK(c, hipGetLastError());
     c->havePlan = true;
     return SPH_OK;
@@ -1244,7 +1261,17 @@ int sph_step_resident(SphCtx *c, const SphParams *p, int32_t nsteps)
         }
         if ((rc = sph_radix_sort(c))) return rc;
         if ((rc = sph_map_table(c))) return rc;
+        // the plan needs the tables only: it runs on the second stream beside the reorder pass
+        // (one is bound by latency, the other by HBM)
+        const bool side = c->stream2 != nullptr;
+        if (side) {
+            HIPCHK(c, hipEventRecord(c->evTable, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evTable, 0));
+            if ((rc = ensure_plan(c, p, c->stream2))) return rc;
+            HIPCHK(c, hipEventRecord(c->evPlan, c->stream2));
+        }
         if ((rc = sph_reorder(c))) return rc;
+        if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evPlan, 0));
         if ((rc = sph_compute_density_and_pressure(c, p))) return rc;
         if ((rc = sph_compute_force(c, p))) return rc;
         keysReady = fuse && s + 1 < nsteps;

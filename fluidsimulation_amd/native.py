@@ -17,8 +17,8 @@ SPH_OK = 0
 SPH_E_INVALID, SPH_E_NOMEM, SPH_E_DEVICE, SPH_E_NODEVICE, SPH_E_TOOLARGE = -1, -2, -3, -4, -5
 
 (SPH_T_KEYS, SPH_T_SORT, SPH_T_TABLE, SPH_T_REORDER, SPH_T_DENSITY, SPH_T_FORCE, SPH_T_INTEGRATE,
- SPH_T_BODIES, SPH_T_COUNT) = range(9)
-STAGE_NAMES = ["keys", "sort", "table", "reorder", "density", "force", "integrate", "bodies"]
+ SPH_T_BODIES, SPH_T_PLAN, SPH_T_COUNT) = range(10)
+STAGE_NAMES = ["keys", "sort", "table", "reorder", "density", "force", "integrate", "bodies", "plan"]
 
 (SPH_BUF_HASHES, SPH_BUF_CELLS, SPH_BUF_KEYS, SPH_BUF_PERM, SPH_BUF_SORTED_KEYS, SPH_BUF_TABLE,
  SPH_BUF_DENSITIES, SPH_BUF_PRESSURES, SPH_BUF_FORCES, SPH_BUF_DENSITY_COUNTS,

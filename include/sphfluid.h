@@ -106,7 +106,8 @@ typedef struct SphGrid {
 /* stage indices of SphTimings.ms */
 enum {
     SPH_T_KEYS = 0, SPH_T_SORT, SPH_T_TABLE, SPH_T_REORDER, SPH_T_DENSITY, SPH_T_FORCE,
-    SPH_T_INTEGRATE, SPH_T_BODIES, SPH_T_COUNT
+    SPH_T_INTEGRATE, SPH_T_BODIES, SPH_T_PLAN /* neighbour plan: overlaps SPH_T_REORDER in sph_step_resident */,
+    SPH_T_COUNT
 };
 typedef struct SphTimings {
     double ms[SPH_T_COUNT];     /* summed device time per stage since sph_reset_timings */

@@ -33,7 +33,7 @@ def test_struct_layouts_match_the_reference_components():
     assert C.sizeof(native.SphParams) == 4 * 14
     assert C.sizeof(native.SphGrid) == 4 * 8
     assert C.sizeof(native.SphConfig) == 16
-    assert C.sizeof(native.SphTimings) == 8 * 8 + 8 * 8 + 8
+    assert C.sizeof(native.SphTimings) == 9 * 8 + 9 * 8 + 8
     assert scene.BOX_FLOATS * 4 == 100
 
 
