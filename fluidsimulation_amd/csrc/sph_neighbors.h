@@ -270,6 +270,43 @@ __device__ __forceinline__ void tile_lookup(HaloTab &h, int tile, const NbArgs &
     __syncthreads();
 }
 
+// the same look-ups for the single-wave plan kernel, in two halves: the loads of the next tile are
+// in flight while the current one is planned (lane l: halo cells l, l + 64, l + 128)
+struct HaloRegs {
+    int2 f[3], b[3];
+};
+__device__ __forceinline__ void tile_lookup_load(HaloRegs &r, int tile, const NbArgs &A)
+{
+    const GridDesc &g = A.g;
+    const int tx = tile % g.ntx, t2 = tile / g.ntx, ty = t2 % g.nty, tz = t2 / g.nty;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int c = (int)threadIdx.x + 64 * i;
+        r.f[i] = r.b[i] = make_int2(0, 0);
+        if (c < NB_HCELLS) {
+            const int hx = c % NB_HX, hy = (c / NB_HX) % NB_HY, hz = c / (NB_HX * NB_HY);
+            const int x = wrapi(tx * SPH_TX + hx - 1, g.gx), y = wrapi(ty * SPH_TY + hy - 1, g.gy),
+                      z = wrapi(tz * SPH_TZ + hz - 1, g.gz);
+            const uint32_t k = tiled_key(x, y, z, g);
+            r.f[i] = A.table[k];
+            if (A.btable) r.b[i] = A.btable[k];
+        }
+    }
+}
+__device__ __forceinline__ void tile_lookup_store(HaloTab &h, const HaloRegs &r)
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int c = (int)threadIdx.x + 64 * i;
+        if (c < NB_HCELLS) {
+            h.fs[c] = r.f[i].x;
+            h.fc[c] = r.f[i].y - r.f[i].x;
+            h.bs[c] = r.b[i].x;
+            h.bc[c] = r.b[i].y - r.b[i].x;
+        }
+    }
+}
+
 __device__ __forceinline__ int tile_halo_index(int x, int y, int z) // tile-local cell + 1
 {
     return (z * NB_HY + y) * NB_HX + x;
@@ -686,29 +723,42 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
 }
 
 // one wave per non-empty tile at a time
-__global__ __launch_bounds__(NB_PTHREADS) void k_plan(NbArgs A)
+__global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_plan(NbArgs A)
 {
     __shared__ PlanShared sh;
     if (threadIdx.x == 0) sh.poolAt = sh.poolEnd = sh.listAt = sh.listEnd = 0;
     const uint32_t ntiles = A.ctl[NB_CTL_TILES];
+    HaloRegs hr;
+    int tile = 0, tileNext = 0;
+    if (blockIdx.x < ntiles) {
+        tile = (int)A.tileList[blockIdx.x];
+        tile_lookup_load(hr, tile, A);
+        if (blockIdx.x + gridDim.x < ntiles) tileNext = (int)A.tileList[blockIdx.x + gridDim.x];
+    }
     for (uint32_t ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
-        const int tile = (int)A.tileList[ti];
-        tile_lookup(sh.h, tile, A);
+        tile_lookup_store(sh.h, hr);
+        wave_lds_fence();
+        const int tileCur = tile;
+        if (ti + gridDim.x < ntiles) { // the next tile's look-ups, and the index of the one after
+            tile = tileNext;
+            tile_lookup_load(hr, tile, A);
+            if (ti + 2 * gridDim.x < ntiles) tileNext = (int)A.tileList[ti + 2 * gridDim.x];
+        }
         // The largest block whose 27-cell halo fits the LDS image: the whole tile, then halves
         // (4x4x1, 4x2x1, 2x2x1) down to single cells, then the global-memory path.  The 32 cells
         // are numbered so that every block is an aligned run: n = z*16 + (y/2)*8 + (x/2)*4 +
         // (y&1)*2 + (x&1).
-        if (plan_block<SPH_TX, SPH_TY, SPH_TZ>(sh, A, tile, 0, 0, 0)) continue;
+        if (plan_block<SPH_TX, SPH_TY, SPH_TZ>(sh, A, tileCur, 0, 0, 0)) continue;
         int cursor = 0, size = SPH_TCELLS / 2;
         while (cursor < SPH_TCELLS) {
             const int bx = ((cursor >> 2) & 1) * 2 + (cursor & 1), by = ((cursor >> 3) & 1) * 2 + ((cursor >> 1) & 1),
                       bz = cursor >> 4;
             bool ok; // one instantiation per shape: the shape is a compile-time constant in each
             switch (size) {
-            case 16: ok = plan_block<4, 4, 1>(sh, A, tile, bx, by, bz); break;
-            case 8: ok = plan_block<4, 2, 1>(sh, A, tile, bx, by, bz); break;
-            case 4: ok = plan_block<2, 2, 1>(sh, A, tile, bx, by, bz); break;
-            default: ok = plan_block<1, 1, 1>(sh, A, tile, bx, by, bz); break;
+            case 16: ok = plan_block<4, 4, 1>(sh, A, tileCur, bx, by, bz); break;
+            case 8: ok = plan_block<4, 2, 1>(sh, A, tileCur, bx, by, bz); break;
+            case 4: ok = plan_block<2, 2, 1>(sh, A, tileCur, bx, by, bz); break;
+            default: ok = plan_block<1, 1, 1>(sh, A, tileCur, bx, by, bz); break;
             }
             if (ok) {
                 cursor += size;
@@ -718,7 +768,7 @@ __global__ __launch_bounds__(NB_PTHREADS) void k_plan(NbArgs A)
             } else {
                 if (threadIdx.x == 0 && sh.h.fc[tile_halo_index(bx + 1, by + 1, bz + 1)] > 0) {
                     const uint32_t idx = atomicAdd(&A.ctl[NB_CTL_GCELLS], 1u);
-                    if (idx < (uint32_t)A.gcellCap) A.gcellList[idx] = make_int2(tile, bx | (by << 8) | (bz << 16));
+                    if (idx < (uint32_t)A.gcellCap) A.gcellList[idx] = make_int2(tileCur, bx | (by << 8) | (bz << 16));
                     else atomicOr(&A.ctl[NB_CTL_ERROR], 2u);
                 }
                 cursor += 1;
@@ -726,7 +776,7 @@ __global__ __launch_bounds__(NB_PTHREADS) void k_plan(NbArgs A)
             const int low = cursor & -cursor; // largest aligned block at the new cursor
             size = low >= 16 ? 16 : low >= 8 ? 8 : low >= 4 ? 4 : 1;
         }
-        __syncthreads(); // sh.h is rewritten by the next tile
+        wave_lds_fence(); // sh.h is rewritten by the next tile
     }
     // the unused entries of this workgroup's last run of the block list: empty blocks
     if (threadIdx.x == 0)
