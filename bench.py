@@ -21,8 +21,9 @@ sys.path.insert(0, ROOT)
 from fluidsimulation_amd import native, scene  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# algorithmic bytes per fluid particle per launch of each stage.  sort is quoted
-# for the passes actually run: 4 + 16*passes for a fused-histogram sort, 20*passes for ours.
+# algorithmic bytes per fluid particle per launch of each stage.  The sort is
+# quoted as SURVEY prescribes, 4 + 16 * passes (one histogram read), although ours re-reads the keys
+# for the histogram of every pass (20 * passes moved): the lower figure is the one priced.
 ALG_BYTES = {"keys": 20, "table": 6, "reorder": 52, "density": 20, "force": 44, "integrate": 68}
 
 
@@ -44,7 +45,9 @@ def cpu_baseline(sc, name):
     FluidSPHByCPUSystem.OnUpdate of the same workload.  Reported, never the target."""
     from oracle import oracle as O
     O.build()
-    threads = min(O.max_threads(), 16)
+    # the GPU box gives one job 16 of the machine's cores (OMP_NUM_THREADS is set to that); nproc
+    # there reports the whole machine
+    threads = min(O.max_threads(), int(os.environ.get("OMP_NUM_THREADS", "16")))
     t0 = time.perf_counter()
     O.sph_step(sc.pos, sc.vel, sc.inv_mass, sc.params, sc.bpos, sc.bparams, sc.grid_size,
                nthreads=threads)
@@ -148,6 +151,9 @@ def main():
         ctx.slab_upload(sc.pos, sc.vel, index, ids, table, sc.grid_size,
                         capacity=sc.n + 4 * buf)
         be = slab.HipSlabBackend(ctx, p, f"cuda:{local}", buffer_records=buf)
+        if os.environ.get("SPH_BENCH_EXCHANGE", "torch") == "native":
+            # the library's own RCCL communicator instead of torch.distributed's send/recv
+            be.init_native_exchange(rank, world)
         sim = slab.SlabSimulation(be, edges, halo=2.0 * sc.grid_size)
         n_local = sc.n
         parallelism = (f"x-slab decomposition over {world} ranks, ghosts within 2h + ownership "
@@ -205,7 +211,7 @@ def main():
         stage_ms = {k: tm["ms"][k] / max(tm["steps"], 1) for k in tm["ms"]}
         _, _, key_bits, _ = ctx.get_grid()
         passes = (key_bits + 7) // 8
-        alg = dict(ALG_BYTES, sort=20 * passes)
+        alg = dict(ALG_BYTES, sort=4 + 16 * passes)
         dom = max((k for k in alg), key=lambda k: stage_ms[k])
         achieved = alg[dom] * n / (stage_ms[dom] * 1e-3) / 1e9
         step_alg = sum(alg.values())
@@ -219,8 +225,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, a.config, n) if world == 1 else None,
-                         "limiter": "fp32 VALU issue (SQ_INSTS_VALU x 4 cycles = 98-99 % of the "
-                                    "kernel's SIMD cycles, profiles/), not HBM",
+                         "limiter": "fp32 VALU issue, not HBM: SQ_INSTS_VALU x 2.6 cycles (measured "
+                                    "issue rate, profiles/r2_microbench_valu.txt) is ~70 % of the "
+                                    "neighbour kernels' SIMD cycles (profiles/r2_*)",
                          "alg_bytes_per_particle": alg[dom],
                          "avg_launch_ms": stage_ms[dom]},
             "step_roofline": {"alg_bytes_per_particle_step": step_alg,

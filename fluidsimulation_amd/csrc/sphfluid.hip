@@ -5,6 +5,8 @@
 #include "../../include/sphfluid.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types only: the library is opened with dlopen in sph_slab_comm_init
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -156,6 +158,13 @@ struct SphCtx {
     int nGhost = 0;     // live ghost records in [0, n)
     int nDead = 0;      // dead records in [0, n), cut off by the next sort
     DevBuf<uint32_t> slabCounters;
+    // native exchange (sph_slab_comm_init / sph_slab_exchange): RCCL communicator, send / receive
+    // buffers of 32-byte records for the two x neighbours, headers (4 words a side)
+    ncclComm_t comm = nullptr;
+    int commRank = 0, commWorld = 0;
+    DevBuf<float4> xsend[2], xrecv[2];
+    DevBuf<uint32_t> xhdr;          // [0..3] recv from left, [4..7] recv from right
+    uint32_t *xhost = nullptr;      // pinned: own counters (4), headers received (8)
 
     // timings
     bool timing = false;
@@ -719,6 +728,7 @@ int sph_destroy(SphCtx *c)
         (void)hipEventDestroy(ep.b);
     }
     for (hipEvent_t e : c->freeEvents) (void)hipEventDestroy(e);
+    (void)sph_slab_comm_destroy(c);
     (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->evTable) (void)hipEventDestroy(c->evTable);
@@ -1805,6 +1815,195 @@ int sph_slab_step_bodies(SphCtx *c, const SphParams *p, const float *impulses, i
     rc = launch_bodies(c, p);
     if (rc) return rc;
     if (impulses) HIPCHK(c, hipStreamSynchronize(c->stream)); // the host array may go away
+    return SPH_OK;
+}
+
+// ---- native exchange over RCCL (SURVEY.md section 5 "distributed communication backend", 8e) ----
+// librccl is opened on first use, so that a process which never exchanges does not load it.
+namespace {
+struct Rccl {
+    void *so = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+Rccl g_rccl;
+std::mutex g_rcclLock;
+
+const char *rccl_open()
+{
+    std::lock_guard<std::mutex> lk(g_rcclLock);
+    if (g_rccl.ok) return nullptr;
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        g_rccl.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.so) break;
+    }
+    if (!g_rccl.so) return "librccl.so not found";
+#define RCCL_SYM(field, sym)                                                                     \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(g_rccl.so, #sym);                               \
+    if (!g_rccl.field) return "librccl.so lacks " #sym;
+    RCCL_SYM(GetUniqueId, ncclGetUniqueId)
+    RCCL_SYM(CommInitRank, ncclCommInitRank)
+    RCCL_SYM(CommDestroy, ncclCommDestroy)
+    RCCL_SYM(GroupStart, ncclGroupStart)
+    RCCL_SYM(GroupEnd, ncclGroupEnd)
+    RCCL_SYM(Send, ncclSend)
+    RCCL_SYM(Recv, ncclRecv)
+    RCCL_SYM(CommGetAsyncError, ncclCommGetAsyncError)
+    RCCL_SYM(GetErrorString, ncclGetErrorString)
+#undef RCCL_SYM
+    g_rccl.ok = true;
+    return nullptr;
+}
+} // namespace
+
+#define RCCLCHK(c, expr)                                                                         \
+    do {                                                                                         \
+        ncclResult_t r_ = (expr);                                                                \
+        if (r_ != ncclSuccess)                                                                   \
+            return fail(c, SPH_E_DEVICE, "%s: %s", #expr, g_rccl.GetErrorString(r_));            \
+    } while (0)
+
+int sph_slab_comm_unique_id(uint8_t *id_out, int32_t cap)
+{
+    if (!id_out || cap < (int32_t)sizeof(ncclUniqueId)) return SPH_E_INVALID;
+    if (const char *e = rccl_open()) return fail(nullptr, SPH_E_DEVICE, "%s", e);
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return fail(nullptr, SPH_E_DEVICE, "ncclGetUniqueId failed");
+    std::memcpy(id_out, &id, sizeof(id));
+    return (int)sizeof(id);
+}
+
+int sph_slab_comm_init(SphCtx *c, int32_t rank, int32_t world, const uint8_t *unique_id, int32_t id_bytes)
+{
+    if (!c) return SPH_E_INVALID;
+    if (world < 1 || rank < 0 || rank >= world || !unique_id || id_bytes != (int32_t)sizeof(ncclUniqueId))
+        return fail(c, SPH_E_INVALID, "sph_slab_comm_init: bad rank / world / unique id");
+    if (c->comm) return fail(c, SPH_E_INVALID, "sph_slab_comm_init: communicator already open");
+    if (const char *e = rccl_open()) return fail(c, SPH_E_DEVICE, "%s", e);
+    if (int rc_ = use_device(c)) return rc_;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    RCCLCHK(c, g_rccl.CommInitRank(&c->comm, world, id, rank));
+    c->commRank = rank;
+    c->commWorld = world;
+    int rc = ensure(c, c->xhdr, 8, false);
+    if (rc) return rc;
+    if (!c->xhost) HIPCHK(c, hipHostMalloc((void **)&c->xhost, 12 * sizeof(uint32_t), hipHostMallocDefault));
+    return SPH_OK;
+}
+
+int sph_slab_comm_destroy(SphCtx *c)
+{
+    if (!c) return SPH_E_INVALID;
+    if (c->comm) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    for (int s = 0; s < 2; s++) { release(c->xsend[s]); release(c->xrecv[s]); }
+    release(c->xhdr);
+    if (c->xhost) (void)hipHostFree(c->xhost);
+    c->xhost = nullptr;
+    return SPH_OK;
+}
+
+// One step's exchange with the two x neighbours, inside the library: count, trade the counts
+// (16 bytes a side), ONE host synchronisation to size the messages, pack, trade the records
+// (ncclSend / ncclRecv in one group, device buffers end to end over xGMI), import.  Everything is
+// ordered on the context's stream; the import kernels are queued behind the receives and nothing
+// waits for them.  counts = records sent left, sent right, received from left, received from right.
+int sph_slab_exchange(SphCtx *c, float xlo, float xhi, float halo, int32_t counts[4])
+{
+    if (!c) return SPH_E_INVALID;
+    if (!c->slab) return fail(c, SPH_E_INVALID, "sph_slab_exchange before sph_slab_upload");
+    if (!c->comm) return fail(c, SPH_E_INVALID, "sph_slab_exchange before sph_slab_comm_init");
+    if (!(halo >= 0.f) || !(xlo <= xhi)) return fail(c, SPH_E_INVALID, "sph_slab_exchange: bad slab");
+    if (int rc_ = use_device(c)) return rc_;
+    const int cur = c->cur, left = c->commRank - 1, right = c->commRank + 1;
+    const bool hasL = left >= 0, hasR = right < c->commWorld;
+    // 1. what this rank will send (no record changes state yet)
+    HIPCHK(c, hipMemsetAsync(c->slabCounters.p, 0, 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->xhdr.p, 0, 32, c->stream));
+    if (c->n > 0)
+        k_slab_pack<true><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
+            nullptr, nullptr, 0, c->slabCounters.p);
+    HIPCHK(c, hipGetLastError());
+    // 2. the counters go to both neighbours as they are: the left one reads words 0 and 2 (records,
+    // transfers towards it), the right one words 1 and 3
+    if (hasL || hasR) {
+        RCCLCHK(c, g_rccl.GroupStart());
+        if (hasL) {
+            RCCLCHK(c, g_rccl.Send(c->slabCounters.p, 16, ncclUint8, left, c->comm, c->stream));
+            RCCLCHK(c, g_rccl.Recv(c->xhdr.p, 16, ncclUint8, left, c->comm, c->stream));
+        }
+        if (hasR) {
+            RCCLCHK(c, g_rccl.Send(c->slabCounters.p, 16, ncclUint8, right, c->comm, c->stream));
+            RCCLCHK(c, g_rccl.Recv(c->xhdr.p + 4, 16, ncclUint8, right, c->comm, c->stream));
+        }
+        RCCLCHK(c, g_rccl.GroupEnd());
+    }
+    HIPCHK(c, hipMemcpyAsync(c->xhost, c->slabCounters.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->xhost + 4, c->xhdr.p, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // the one host synchronisation of the step
+    {
+        ncclResult_t async = ncclSuccess;
+        RCCLCHK(c, g_rccl.CommGetAsyncError(c->comm, &async));
+        if (async != ncclSuccess)
+            return fail(c, SPH_E_DEVICE, "RCCL asynchronous error: %s", g_rccl.GetErrorString(async));
+    }
+    const uint32_t *h = c->xhost;
+    // a neighbour sends to its right (words 1, 3) what arrives here from the left, and vice versa
+    const uint32_t sendN[2] = {hasL ? h[0] : 0u, hasR ? h[1] : 0u};
+    const uint32_t recvN[2] = {hasL ? h[4 + 1] : 0u, hasR ? h[8 + 0] : 0u};
+    const uint32_t recvT[2] = {hasL ? h[4 + 3] : 0u, hasR ? h[8 + 2] : 0u};
+    const uint32_t capSend = std::max(std::max(h[0], h[1]), 1u);
+    int rc = SPH_OK;
+    for (int s = 0; s < 2 && !rc; s++) {
+        rc = ensure(c, c->xsend[s], 2 * (size_t)capSend);
+        if (!rc) rc = ensure(c, c->xrecv[s], 2 * (size_t)std::max(recvN[s], 1u));
+    }
+    if (rc) return rc;
+    const uint32_t cap = (uint32_t)std::min<size_t>(std::min(c->xsend[0].cap, c->xsend[1].cap) / 2, 1u << 30);
+    // 3. pack: last step's ghosts die, the particles that left stay as this step's ghosts
+    HIPCHK(c, hipMemsetAsync(c->slabCounters.p, 0, 16, c->stream));
+    if (c->n > 0)
+        k_slab_pack<false><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
+            c->xsend[0].p, c->xsend[1].p, (int)cap, c->slabCounters.p);
+    HIPCHK(c, hipGetLastError());
+    const int moved = (int)((hasL ? h[2] : 0u) + (hasR ? h[3] : 0u));
+    // (particles beyond an outer rank's open side are not sent anywhere: xlo / xhi are infinite there)
+    c->nDead += c->nGhost;
+    c->nGhost = (int)(h[2] + h[3]);
+    c->nOwned -= (int)(h[2] + h[3]);
+    (void)moved;
+    // 4. the records
+    if (sendN[0] + sendN[1] + recvN[0] + recvN[1] > 0) {
+        RCCLCHK(c, g_rccl.GroupStart());
+        if (sendN[0]) RCCLCHK(c, g_rccl.Send(c->xsend[0].p, (size_t)sendN[0] * 32, ncclUint8, left, c->comm, c->stream));
+        if (sendN[1]) RCCLCHK(c, g_rccl.Send(c->xsend[1].p, (size_t)sendN[1] * 32, ncclUint8, right, c->comm, c->stream));
+        if (recvN[0]) RCCLCHK(c, g_rccl.Recv(c->xrecv[0].p, (size_t)recvN[0] * 32, ncclUint8, left, c->comm, c->stream));
+        if (recvN[1]) RCCLCHK(c, g_rccl.Recv(c->xrecv[1].p, (size_t)recvN[1] * 32, ncclUint8, right, c->comm, c->stream));
+        RCCLCHK(c, g_rccl.GroupEnd());
+    }
+    // 5. append what arrived (queued behind the receives on the same stream)
+    for (int s = 0; s < 2; s++)
+        if (recvN[s] && (rc = sph_slab_import(c, c->xrecv[s].p, (int32_t)recvN[s], (int32_t)recvT[s]))) return rc;
+    if (counts) {
+        counts[0] = (int32_t)sendN[0];
+        counts[1] = (int32_t)sendN[1];
+        counts[2] = (int32_t)recvN[0];
+        counts[3] = (int32_t)recvN[1];
+    }
     return SPH_OK;
 }
 

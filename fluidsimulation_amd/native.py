@@ -40,6 +40,7 @@ EXPORTS = [
     "sph_sort_pairs", "sph_sort_pairs_noalloc", "sph_get_timings", "sph_reset_timings",
     "sph_slab_upload", "sph_slab_pack", "sph_slab_import", "sph_slab_counts", "sph_slab_download",
     "sph_slab_step_particles", "sph_slab_get_impulses", "sph_slab_step_bodies",
+    "sph_slab_comm_unique_id", "sph_slab_comm_init", "sph_slab_exchange", "sph_slab_comm_destroy",
 ]
 
 
@@ -128,6 +129,10 @@ def load():
     lib.sph_slab_get_impulses.argtypes = [vp, vp, i32]
     lib.sph_slab_step_bodies.argtypes = [vp, C.POINTER(SphParams), vp, i32]
     lib.sph_slab_download.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(i32)]
+    lib.sph_slab_comm_unique_id.argtypes = [vp, i32]
+    lib.sph_slab_comm_init.argtypes = [vp, i32, i32, vp, i32]
+    lib.sph_slab_exchange.argtypes = [vp, f32, f32, f32, C.POINTER(i32 * 4)]
+    lib.sph_slab_comm_destroy.argtypes = [vp]
     for name in EXPORTS:
         if name not in ("sph_last_error", "sph_find_grid_size"):
             getattr(lib, name).restype = C.c_int
@@ -385,6 +390,28 @@ class Context:
         self.last_slab_pack_counts = list(counts)   # on SPH_E_TOOLARGE: what the buffers need
         self._chk(rc)
         return list(counts)
+
+    @staticmethod
+    def slab_comm_unique_id():
+        """128 bytes from ncclGetUniqueId (rank 0; the launcher carries them to every rank)"""
+        buf = (C.c_uint8 * 128)()
+        n = load().sph_slab_comm_unique_id(buf, 128)
+        if n < 0:
+            raise SphError(n, load().sph_last_error(None).decode())
+        return bytes(buf[:n])
+
+    def slab_comm_init(self, rank, world, unique_id):
+        buf = (C.c_uint8 * len(unique_id)).from_buffer_copy(unique_id)
+        self._chk(self.lib.sph_slab_comm_init(self.h, rank, world, buf, len(unique_id)))
+
+    def slab_exchange(self, xlo, xhi, halo):
+        """pack + RCCL send/recv with both x neighbours + import, inside the library"""
+        counts = (C.c_int32 * 4)()
+        self._chk(self.lib.sph_slab_exchange(self.h, xlo, xhi, halo, C.byref(counts)))
+        return list(counts)
+
+    def slab_comm_destroy(self):
+        self._chk(self.lib.sph_slab_comm_destroy(self.h))
 
     def slab_import(self, records_ptr, count, transfers):
         self._chk(self.lib.sph_slab_import(self.h, records_ptr, count, transfers))

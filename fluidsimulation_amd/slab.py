@@ -106,6 +106,18 @@ class HipSlabBackend:
         self.cap = int(buffer_records)
         self._alloc(self.cap)
         self._keep = []        # received buffers the library may still be reading
+        self.native_exchange = False
+
+    def init_native_exchange(self, rank, world, group=None):
+        """Opens the library's own RCCL communicator (sph_slab_comm_init): rank 0 draws the
+        unique id, torch.distributed only carries its 128 bytes to the other ranks.  From then on
+        SlabSimulation.exchange is one sph_slab_exchange call per step."""
+        box = [native.Context.slab_comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                       group=group)
+        self.ctx.slab_comm_init(rank, world, box[0])
+        self.native_exchange = True
 
     def _alloc(self, cap):
         self.cap = int(cap)
@@ -261,6 +273,12 @@ class SlabSimulation:
         return result
 
     def exchange(self):
+        if getattr(self.backend, "native_exchange", False):
+            # pack, ncclSend / ncclRecv with both neighbours and import inside the library
+            sl, sr, rl, rr = self.backend.ctx.slab_exchange(self.xlo, self.xhi, self.halo)
+            self.sent_records += sl + sr
+            self.received_records += rl + rr
+            return
         left, right, counts = self.backend.pack(self.xlo, self.xhi, self.halo)
         self.transfers_out += counts[2] + counts[3]
         for records, transfers in self._exchange(left, right, counts):

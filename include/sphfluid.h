@@ -292,6 +292,22 @@ SPH_API int sph_slab_step_particles(SphCtx *ctx, const SphParams *p);
 SPH_API int sph_slab_get_impulses(SphCtx *ctx, float *impulses_out /* K*6 */, int32_t K);
 SPH_API int sph_slab_step_bodies(SphCtx *ctx, const SphParams *p, const float *impulses /* K*6 */,
                                  int32_t K);
+/* Native exchange: the same step, with the transport inside the library (RCCL ncclSend / ncclRecv
+ * between x neighbours over xGMI, opened with dlopen on first use), for hosts that have no
+ * communication layer of their own (the C# host).  No counterpart in the reference.
+ *   rank 0: sph_slab_comm_unique_id -> 128 bytes, carried to every rank by the launcher (returns
+ *           the number of bytes written, or a negative code)
+ *   all:    sph_slab_comm_init(rank, world, id) once, after sph_create (collective)
+ *   per step: sph_slab_exchange(xlo, xhi, halo) = sph_slab_pack + send/recv with both neighbours +
+ *           sph_slab_import, on the context's stream, with ONE host synchronisation (the sizes of
+ *           the messages); then sph_step_resident / sph_slab_step_particles as above.
+ *           counts = records sent left, sent right, received from left, received from right.
+ * Rank r's neighbours are r-1 and r+1; pass -INF / +INF as xlo / xhi on the outer ranks. */
+SPH_API int sph_slab_comm_unique_id(uint8_t *id_out, int32_t cap);
+SPH_API int sph_slab_comm_init(SphCtx *ctx, int32_t rank, int32_t world, const uint8_t *unique_id,
+                               int32_t id_bytes);
+SPH_API int sph_slab_exchange(SphCtx *ctx, float xlo, float xhi, float halo, int32_t counts[4]);
+SPH_API int sph_slab_comm_destroy(SphCtx *ctx);
 /* counts = records resident, owned, live ghosts, dead ghosts */
 SPH_API int sph_slab_counts(SphCtx *ctx, int32_t counts[4]);
 /* the owned particles, host arrays, in the resident order; density_out is zero-filled unless a

@@ -187,3 +187,46 @@ def test_slab_cuts_move_on_the_gpu(tmp_path):
     v = run_ranks("hip", 2, 5, tmp_path, rebalance=True)
     check(v, 1e-5)
     assert v["final_edges"][0] < 4.6     # the cut started at 60 % of the block and moved left
+
+
+@pytest.mark.gpu
+def test_native_rccl_exchange_world_of_one():
+    """sph_slab_comm_init / sph_slab_exchange through the C ABI with a real RCCL communicator of
+    one rank (the GPU box has one device; RCCL refuses two ranks on one GPU): the unique id, the
+    communicator, the count / pack / import sequence on the library's stream, the bookkeeping, and
+    that a run driven by sph_slab_exchange equals the run driven by sph_slab_pack bit for bit.  The
+    two-neighbour message pattern itself is what the gloo tests above rehearse rank by rank."""
+    import numpy as np
+    import torch
+    from fluidsimulation_amd import native, scene
+    sc = scene.dam_break(6, 6, 6, jitter_seed=11)
+    mats = np.array([[0.25, 1000, 256, 512, 1 / 125]], np.float32)
+    idx = np.zeros(sc.n, np.uint32)
+    ids = np.arange(sc.n, dtype=np.uint32)
+    p = native.make_params(sc.grid_size)
+    uid = native.Context.slab_comm_unique_id()
+    assert len(uid) == 128
+    out = []
+    for use_native in (True, False):
+        with native.Context(device=0) as ctx:
+            ctx.set_boundary(sc.bpos, sc.bparams)
+            ctx.slab_upload(sc.pos, sc.vel, idx, ids, mats, sc.grid_size, capacity=2 * sc.n)
+            if use_native:
+                with pytest.raises(native.SphError):   # exchange before the communicator exists
+                    ctx.slab_exchange(-np.inf, np.inf, 2.0)
+                ctx.slab_comm_init(0, 1, uid)
+                with pytest.raises(native.SphError):   # a second communicator on one context
+                    ctx.slab_comm_init(0, 1, uid)
+            rec = torch.zeros((16, 8), dtype=torch.float32, device="cuda:0")
+            for _ in range(3):
+                if use_native:
+                    assert ctx.slab_exchange(-np.inf, np.inf, 2.0) == [0, 0, 0, 0]
+                else:
+                    assert ctx.slab_pack(-np.inf, np.inf, 2.0, rec.data_ptr(), rec.data_ptr(), 8) == [0, 0, 0, 0]
+                ctx.step_resident(p, 1)
+            assert ctx.slab_counts() == {"resident": sc.n, "owned": sc.n, "ghosts": 0, "dead": 0}
+            out.append(ctx.slab_download())
+            if use_native:
+                ctx.slab_comm_destroy()
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
