@@ -239,16 +239,29 @@ def main():
             out["slab_rank0"] = slab_info
         if world == 1 and not a.no_host_round_trip:
             # the span FluidSPHByGPUSystem.cs:227-252 pays every frame: upload, step, download of
-            # caller-owned host arrays (pageable memory) -- reported beside `value`, never as it
-            hp, hv = pos.copy(), vel.copy()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                hp, hv, _, _ = ctx.step(p, hp, hv, sc.inv_mass, sc.params)
-            rt = (time.perf_counter() - t1) / 3
+            # caller-owned host arrays -- reported beside `value`, never as it.  Twice: from
+            # pageable memory, and with SphConfig.pinHostArrays (the arrays registered once, as a
+            # host with persistent NativeArrays would run it)
+            def round_trip(c2, frames):
+                hp, hv = pos.copy(), vel.copy()
+                c2.set_boundary(sc.bpos, sc.bparams)
+                c2.set_colliders(sc.boxes)
+                c2.step_inplace(p, hp, hv, sc.inv_mass, sc.params)   # first frame: allocations, pinning
+                t1 = time.perf_counter()
+                for _ in range(frames):
+                    c2.step_inplace(p, hp, hv, sc.inv_mass, sc.params)
+                return (time.perf_counter() - t1) / frames
+            ctx.close()
+            with native.Context(device=local) as c2:
+                rt = round_trip(c2, 3)
+            with native.Context(device=local, pin_host_arrays=True) as c2:
+                rtp = round_trip(c2, 3)
             out["host_round_trip"] = {"ms_per_step": rt * 1e3, "value": n / rt,
+                                      "ms_per_step_pinned": rtp * 1e3, "value_pinned": n / rtp,
                                       "unit": "particle-updates/s",
-                                      "what": "sph_step: upload 44 B + step + download 24 B per "
-                                              "particle, 3 frames"}
+                                      "what": "sph_step: upload 24 B + step + download 24 B per "
+                                              "particle on the caller's arrays, 3 frames after a "
+                                              "first one; pageable / registered host memory"}
         if not a.no_cpu_baseline and world == 1:
             bsc = sc if not a.cpu_baseline_config else scene.make_config(a.cpu_baseline_config)
             out["cpu_baseline"] = cpu_baseline(bsc, a.cpu_baseline_config or a.config)

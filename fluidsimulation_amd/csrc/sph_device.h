@@ -56,6 +56,7 @@ struct DevBox {
     float invI[3];
     float restitution;
     int dynamic;
+    float amin[3], amax[3]; // world AABB of the box (k_bodies): broadphase of k_apply_integrate
 };
 
 __device__ __forceinline__ int wrap_cell(int c, int g)

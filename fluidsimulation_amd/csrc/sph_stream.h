@@ -228,10 +228,32 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
         const float r = m.radius;
 #pragma unroll
         for (int a = 0; a < 3; a++) x[a] = x[a] + v[a] * dt;
+        // Broadphase: the particles of a wave are neighbours in the sorted order (a few cells), so
+        // the wave's own bounds (spheres included) are tested against each box's world AABB with
+        // scalar compares and the whole wave skips a box it cannot touch.  Exact: a box that is
+        // skipped would have changed nothing; the bounds are taken again after any push-out.
+        float wmin[3], wmax[3];
+        auto wave_bounds = [&]() {
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                float lo = live ? x[a] - r : 3.0e38f, hi = live ? x[a] + r : -3.0e38f;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    lo = fminf(lo, __shfl_xor(lo, d, 64));
+                    hi = fmaxf(hi, __shfl_xor(hi, d, 64));
+                }
+                wmin[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lo)));
+                wmax[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hi)));
+            }
+        };
+        if (nboxes > 0) wave_bounds();
         for (int k = 0; k < nboxes; k++) {
             const DevBox &bx = boxes[k];
+            if (wmax[0] < bx.amin[0] || wmin[0] > bx.amax[0] || wmax[1] < bx.amin[1] ||
+                wmin[1] > bx.amax[1] || wmax[2] < bx.amin[2] || wmin[2] > bx.amax[2])
+                continue; // wave-uniform
             float imp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            bool pushed = false;
+            bool pushed = false, touched = false;
             if (live) {
                 const float d[3] = {x[0] - bx.c[0], x[1] - bx.c[1], x[2] - bx.c[2]};
                 float p[3], delta[3], nl[3] = {0.f, 0.f, 0.f}, pen = 0.f;
@@ -265,6 +287,7 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
                     pen = bestd + r;
                     contact = true;
                 }
+                touched = contact;
                 if (contact) {
                     float nw[3];
                     nw[0] = (bx.R[0] * nl[0] + bx.R[1] * nl[1]) + bx.R[2] * nl[2];
@@ -326,6 +349,7 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
                     if (lane_id() == 0) atomicAdd(&bodyImpulse[6 * k + a], t);
                 }
             }
+            if (__any(touched)) wave_bounds(); // positions were pushed out of the box
         }
     }
     if (live) {
@@ -418,6 +442,11 @@ __global__ void k_bodies(float *__restrict__ state, DevBox *__restrict__ dev,
     d.invMass = invMass;
     d.restitution = b[20];
     d.dynamic = dynamic ? 1 : 0;
+    for (int a = 0; a < 3; a++) {
+        const float ext = (fabsf(m[3 * a]) * he[0] + fabsf(m[3 * a + 1]) * he[1]) + fabsf(m[3 * a + 2]) * he[2];
+        d.amin[a] = center[a] - ext;
+        d.amax[a] = center[a] + ext;
+    }
     dev[k] = d;
     for (int a = 0; a < 6; a++) bodyImpulse[6 * k + a] = 0.f;
 }

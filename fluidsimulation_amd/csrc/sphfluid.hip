@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -115,6 +116,12 @@ struct SphCtx {
     DevBuf<Mat> dmats;
     std::unordered_map<MatKey, uint32_t, MatKeyHash> matIndex;
     std::vector<uint32_t> hostMatIdx;
+    bool matUniform = false; // every particle of the last upload carries material 0
+    // SphConfig.pinHostArrays: caller arrays registered with the driver (page-locked) on first
+    // use and kept, so that the per-frame copies of the host round trips run as DMA at PCIe rate
+    bool pinHost = false;
+    struct Pinned { const void *p; size_t bytes; };
+    std::vector<Pinned> pinned;
 
     // grid
     GridDesc grid{};
@@ -339,6 +346,35 @@ void build_materials(SphCtx *c, const float *invMass, const SphParticle *params,
 {
     c->matKeys.clear();
     c->matIndex.clear();
+    c->matUniform = false;
+    // the usual frame: one fluid, every particle with the same five numbers.  A scan in a few
+    // threads settles that (memory-bound, ~20 B per particle); the index array is then all zeros
+    // and is neither built nor uploaded.
+    if (n >= (1 << 16)) {
+        const int nt = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<int> same((size_t)nt, 1);
+        std::vector<std::thread> th;
+        const SphParticle p0 = params[0];
+        const float m0 = invMass[0];
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                const size_t lo = (size_t)n * t / nt, hi = (size_t)n * (t + 1) / nt;
+                bool ok = true;
+                for (size_t i = lo; i < hi && ok; i++)
+                    ok = std::memcmp(&params[i], &p0, 16) == 0 && std::memcmp(&invMass[i], &m0, 4) == 0;
+                same[(size_t)t] = ok ? 1 : 0;
+            });
+        for (auto &x : th) x.join();
+        if (std::all_of(same.begin(), same.end(), [](int v) { return v == 1; })) {
+            MatKey k;
+            std::memcpy(&k.w[0], &p0, 16);
+            std::memcpy(&k.w[4], &m0, 4);
+            c->matKeys.push_back(k);
+            c->matIndex.emplace(k, 0u);
+            c->matUniform = true;
+            return;
+        }
+    }
     c->hostMatIdx.resize((size_t)n);
     MatKey last{};
     uint32_t lastIdx = 0;
@@ -685,6 +721,7 @@ int sph_create(const SphConfig *cfg, SphCtx **out)
     }
     if (cfg && cfg->maxCells > 0) c->maxCells = std::max(cfg->maxCells, 64);
     c->timing = cfg && cfg->enableTimings;
+    c->pinHost = cfg && cfg->pinHostArrays;
     *out = c;
     return SPH_OK;
 }
@@ -729,6 +766,8 @@ int sph_destroy(SphCtx *c)
     }
     for (hipEvent_t e : c->freeEvents) (void)hipEventDestroy(e);
     (void)sph_slab_comm_destroy(c);
+    for (auto &e : c->pinned)
+        if (e.bytes) (void)hipHostUnregister(const_cast<void *>(e.p));
     (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->evTable) (void)hipEventDestroy(c->evTable);
@@ -889,6 +928,31 @@ int sph_get_grid(SphCtx *c, SphGrid *g)
     return SPH_OK;
 }
 
+// Registers a caller array with the driver once (SphConfig.pinHostArrays) and remembers it; a
+// failure is not an error, the copy then runs from pageable memory as before.  At most 16 arrays
+// are kept, the oldest is released first.
+static void pin_host(SphCtx *c, const void *p, size_t bytes)
+{
+    if (!c->pinHost || !p || bytes < (1u << 20)) return;
+    for (auto &e : c->pinned)
+        if (e.p == p) {
+            if (e.bytes >= bytes) return;
+            (void)hipHostUnregister(const_cast<void *>(p));
+            e.bytes = 0;
+            if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) e.bytes = bytes;
+            else (void)hipGetLastError();
+            return;
+        }
+    if (c->pinned.size() >= 16) {
+        if (c->pinned.front().bytes) (void)hipHostUnregister(const_cast<void *>(c->pinned.front().p));
+        c->pinned.erase(c->pinned.begin());
+    }
+    size_t got = 0;
+    if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) got = bytes;
+    else (void)hipGetLastError();
+    c->pinned.push_back({p, got});
+}
+
 int sph_upload(SphCtx *c, const float *pos, const float *vel, const float *invMass,
                const SphParticle *params, int32_t N, float gridSize)
 {
@@ -910,10 +974,15 @@ int sph_upload(SphCtx *c, const float *pos, const float *vel, const float *invMa
     c->cur = 0;
     c->slab = false;
     c->nOwned = c->nGhost = c->nDead = 0;
+    pin_host(c, pos, (size_t)12 * N);
+    pin_host(c, vel, (size_t)12 * N);
     HIPCHK(c, hipMemcpyAsync(c->io3a.p, pos, (size_t)12 * N, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->io3b.p, vel, (size_t)12 * N, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->ioU.p, c->hostMatIdx.data(), (size_t)4 * N, hipMemcpyHostToDevice,
-                             c->stream));
+    if (c->matUniform)
+        HIPCHK(c, hipMemsetAsync(c->ioU.p, 0, (size_t)4 * N, c->stream));
+    else
+        HIPCHK(c, hipMemcpyAsync(c->ioU.p, c->hostMatIdx.data(), (size_t)4 * N, hipMemcpyHostToDevice,
+                                 c->stream));
     k_pack_fluid<<<blocks_for(N, 256), 256, 0, c->stream>>>(c->io3a.p, c->io3b.p, c->ioU.p,
                                                             c->dmats.p, N, c->posm[0].p,
                                                             c->velq[0].p, c->mat[0].p, c->oid[0].p);
@@ -944,6 +1013,8 @@ int sph_download(SphCtx *c, float *pos_out, float *vel_out)
     if (!rc) rc = check_plan_error(c);
     if (rc) return rc;
     const int cur = c->cur;
+    pin_host(c, pos_out, (size_t)12 * N);
+    pin_host(c, vel_out, (size_t)12 * N);
     if (pos_out) {
         k_unpack3<<<blocks_for(N, 256), 256, 0, c->stream>>>(c->posm[cur].p, c->oid[cur].p, N,
                                                              c->io3a.p);
@@ -1378,6 +1449,7 @@ static int read_ecs(SphCtx *c, int32_t buffer, void *out)
     default: return fail(c, SPH_E_INVALID, "buffer %d is not an ECS-order buffer", buffer);
     }
     HIPCHK(c, hipGetLastError());
+    pin_host(c, out, bytes);
     HIPCHK(c, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPH_OK;

@@ -53,7 +53,7 @@ class SphParams(C.Structure):
 
 class SphConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("maxCells", C.c_int32), ("enableTimings", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("pinHostArrays", C.c_int32)]
 
 
 class SphGrid(C.Structure):
@@ -167,9 +167,11 @@ def _f32(a, shape=None):
 class Context:
     """Thin RAII wrapper over SphCtx*; methods map 1:1 to the C entry points."""
 
-    def __init__(self, device=0, max_cells=0, timings=False):
+    def __init__(self, device=0, max_cells=0, timings=False, pin_host_arrays=False):
+        """pin_host_arrays: SphConfig.pinHostArrays -- only with arrays that come back every frame
+        and outlive the context (step_inplace), never with temporaries"""
         self.lib = load()
-        cfg = SphConfig(device, max_cells, 1 if timings else 0, 0)
+        cfg = SphConfig(device, max_cells, 1 if timings else 0, 1 if pin_host_arrays else 0)
         h = C.c_void_p()
         rc = self.lib.sph_create(C.byref(cfg), C.byref(h))
         if rc != SPH_OK:
@@ -305,6 +307,16 @@ class Context:
         self._chk(self.lib.sph_step(self.h, C.byref(p), _ptr(pos), _ptr(vel), _ptr(inv_mass),
                                     _ptr(params), n, _ptr(dens), _ptr(forces)))
         return pos, vel, dens, forces
+
+    def step_inplace(self, p, pos, vel, inv_mass, params, dens=None, forces=None):
+        """sph_step on the caller's own arrays, as the C# host calls it: pos / vel are read and
+        overwritten, nothing is copied on the Python side"""
+        for a in (pos, vel, inv_mass, params):
+            assert a.dtype == np.float32 and a.flags.c_contiguous
+        n = len(pos)
+        self.n = n
+        self._chk(self.lib.sph_step(self.h, C.byref(p), _ptr(pos), _ptr(vel), _ptr(inv_mass),
+                                    _ptr(params), n, _ptr(dens), _ptr(forces)))
 
     def step_compat(self, p, pos, vel, inv_mass, params):
         pos, vel = _f32(pos, (-1, 3)), _f32(vel, (-1, 3))

@@ -74,7 +74,7 @@ public unsafe partial class FluidSPHByHIPSystem : SystemBase
     bool OpenDevice()
     {
         if (m_Ctx != IntPtr.Zero) return true;
-        var cfg = new SphNative.SphConfig { device = 0, maxCells = 0, enableTimings = 0, reserved = 0 };
+        var cfg = new SphNative.SphConfig { device = 0, maxCells = 0, enableTimings = 0, pinHostArrays = 1 };
         int rc = SphNative.sph_create(&cfg, out m_Ctx);
         if (rc == SphNative.SPH_OK) return true;
         // no gfx950 device: leave the frame to the project's own GPU / CPU systems

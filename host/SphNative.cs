@@ -82,7 +82,7 @@ public static unsafe class SphNative
         public int device;
         public int maxCells;
         public int enableTimings;
-        public int reserved;
+        public int pinHostArrays;
     }
 
     [StructLayout(LayoutKind.Sequential)]

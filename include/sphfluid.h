@@ -89,7 +89,10 @@ typedef struct SphConfig {
     int32_t device;          /* HIP device ordinal */
     int32_t maxCells;        /* cap on the periodic cell table (0 = default 1<<25)  */
     int32_t enableTimings;   /* record HIP events per stage (sph_get_timings)        */
-    int32_t reserved;
+    int32_t pinHostArrays;   /* !=0: caller arrays of sph_upload / sph_download / sph_step* are
+                                registered with the driver on first use (hipHostRegister) and stay
+                                registered until sph_destroy: use it when the same arrays come
+                                back every frame and outlive the context (persistent NativeArrays) */
 } SphConfig;
 
 /* Periodic cell table the dense sort key is built on (DESIGN.md "cell keys").  A particle in

@@ -333,6 +333,42 @@ def test_many_dynamic_boxes_two_rest_densities(ctx, oracle):
     assert np.all(moved > 1e-3)                 # every dynamic box was actually pushed / fell
 
 
+def test_a_thousand_colliders(ctx, oracle):
+    """K = 1024 boxes (1000 small static obstacles in a lattice through the fluid, rotated at
+    random, plus 18 dynamic ones and the 6 walls): the broadphase of the integrate kernel (wave
+    bounds against box AABBs) must skip nothing that matters -- particle and body state against
+    the oracle, which tests every particle against every box in order."""
+    rng = np.random.default_rng(77)
+    sc = _many_body_scene(22, nbodies=18)
+    L = sc.tank_max - sc.tank_min
+    obstacles = []
+    for k in range(1000):
+        ix, iy, iz = k % 10, (k // 10) % 10, k // 100
+        c = sc.tank_min + (np.array([ix, iy, iz]) + 0.5) / 10.0 * L + rng.uniform(-0.1, 0.1, 3)
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        obstacles.append(scene.static_box(c, rng.uniform(0.05, 0.2, 3), rotation=q, restitution=0.3))
+    sc.boxes = np.concatenate([sc.boxes, np.stack(obstacles).astype(np.float32)], axis=0)
+    assert len(sc.boxes) == 1024
+    nsteps = 2
+    bounds = (sc.tank_min, sc.tank_max)
+    load_scene(ctx, sc, debug=0, colliders=True)
+    p = native.make_params(sc.grid_size, body_bounds=bounds)
+    ctx.step_resident(p, nsteps)
+    gpos, gvel = ctx.download()
+    gbox = ctx.get_colliders()
+    opos, ovel, oboxes = oracle_steps(oracle, sc, nsteps, bounds=bounds)
+    assert_close(gpos, opos, rtol=2e-5, what="position")
+    assert_close(gvel, ovel, rtol=2e-5, what="velocity")
+    assert_close(gbox[:, 0:3], oboxes[:, 0:3], rtol=2e-5, what="body centre")
+    assert_close(gbox[:, 10:16], oboxes[:, 10:16], rtol=1e-4, what="body velocities")
+    # the obstacles did deflect particles: the run without them differs
+    sc2 = _many_body_scene(22, nbodies=18)
+    load_scene(ctx, sc2, debug=0, colliders=True)
+    ctx.step_resident(p, nsteps)
+    assert np.abs(ctx.download()[0] - gpos).max() > 1e-3
+
+
 def test_find_bounds_matches_oracle(ctx, oracle):
     """FindBoundsJob's snapped AABB (FluidSPHUtils.cs:57-93, +1f on the max, :85-92), fluid and
     boundary particles together; compared bit for bit"""
