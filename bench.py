@@ -230,6 +230,11 @@ def main():
                                     "neighbour kernels' SIMD cycles (profiles/r2_*)",
                          "alg_bytes_per_particle": alg[dom],
                          "avg_launch_ms": stage_ms[dom]},
+            # the two neighbour kernels take nearly the same time: both fractions, whichever leads
+            "neighbour_kernels": {k: {"alg_bytes_per_particle": alg[k], "avg_launch_ms": stage_ms[k],
+                                      "achieved_GBs": alg[k] * n / (stage_ms[k] * 1e-3) / 1e9,
+                                      "frac": alg[k] * n / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                  for k in ("density", "force")},
             "step_roofline": {"alg_bytes_per_particle_step": step_alg,
                               "achieved_GBs": step_alg * n / (ms_step * 1e-3) / 1e9,
                               "frac": step_alg * n / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},

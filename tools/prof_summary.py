@@ -14,7 +14,7 @@ def short(name):
     name = name.split("(")[0]
     for k in ("k_density", "k_force", "k_radix_hist", "k_radix_scan", "k_radix_scatter",
               "k_map_table", "k_reorder", "k_keys", "k_apply_integrate", "k_bodies", "k_pack",
-              "k_unpack", "k_bounds", "k_gather4"):
+              "k_unpack", "k_bounds", "k_gather4", "k_plan", "k_tile_list"):
         if k in name:
             return k
     return name[:40]
@@ -63,3 +63,18 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
         for k in acc:
             s = " ".join(f"{c}={acc[k][c]/cnt[k][c]:.4g}" for c in sorted(acc[k]))
             print(f"{k:34s} n={max(cnt[k].values()):4d} {s}")
+        # VALU issue utilisation, normalised by SQ_BUSY_CYCLES (summed over the chip's 32 SQ
+        # instances, so /32 = the launch's cycles): instructions x measured issue cost (2.6 cycles
+        # per wave64 instruction per SIMD with >= 2 waves, profiles/r2_microbench_valu.txt) over
+        # 1024 SIMDs x cycles
+        lines = []
+        for k in acc:
+            if "SQ_BUSY_CYCLES" in acc[k] and "SQ_INSTS_VALU" in acc[k]:
+                busy = acc[k]["SQ_BUSY_CYCLES"] / cnt[k]["SQ_BUSY_CYCLES"] / 32.0
+                valu = acc[k]["SQ_INSTS_VALU"] / cnt[k]["SQ_INSTS_VALU"]
+                if busy > 1e5:
+                    lines.append(f"{k:34s} cycles={busy:.4g} VALU/SIMD={valu / 1024:.4g} "
+                                 f"issue utilisation at 2.6 cyc = {valu / 1024 * 2.6 / busy:.2f}")
+        if lines:
+            print("== VALU issue utilisation (SQ_BUSY_CYCLES-normalised)")
+            print("\n".join(lines))
