@@ -401,8 +401,51 @@ __global__ void k_bodies(float *__restrict__ state, DevBox *__restrict__ dev,
         for (int a = 0; a < 3; a++) {
             lv[a] = (lv[a] + imp[a] * invMass + g[a] * gfac * dt) * ld;
             av[a] = (av[a] + dw[a]) * ad;
-            center[a] = center[a] + lv[a] * dt;
         }
+        // contacts of the box's eight corners with the six planes of [bmin,bmax] (the tank's
+        // walls): four passes of sequential impulses (ConvertedSubScene.unity:235), speculative,
+        // inelastic, frictionless (geometric mean with the walls' friction 0, :742-746)
+        if (bounded) {
+            for (int it = 0; it < 4; it++)
+                for (int corner = 0; corner < 8; corner++) {
+                    const float hl[3] = {(corner & 1) ? he[0] : -he[0], (corner & 2) ? he[1] : -he[1],
+                                         (corner & 4) ? he[2] : -he[2]};
+                    float r[3];
+                    r[0] = (m[0] * hl[0] + m[1] * hl[1]) + m[2] * hl[2];
+                    r[1] = (m[3] * hl[0] + m[4] * hl[1]) + m[5] * hl[2];
+                    r[2] = (m[6] * hl[0] + m[7] * hl[1]) + m[8] * hl[2];
+                    for (int a = 0; a < 3; a++)
+                        for (int side = 0; side < 2; side++) {
+                            const float vc[3] = {lv[0] + (av[1] * r[2] - av[2] * r[1]),
+                                                 lv[1] + (av[2] * r[0] - av[0] * r[2]),
+                                                 lv[2] + (av[0] * r[1] - av[1] * r[0])};
+                            const float sgn = side ? -1.0f : 1.0f;
+                            const float pc = center[a] + r[a];
+                            const float gap = side ? bmax[a] - pc : pc - bmin[a];
+                            const float need = -gap / dt - sgn * vc[a];
+                            if (need > 0.0f) {
+                                float n[3] = {0.0f, 0.0f, 0.0f};
+                                n[a] = sgn;
+                                const float rxn[3] = {r[1] * n[2] - r[2] * n[1], r[2] * n[0] - r[0] * n[2],
+                                                      r[0] * n[1] - r[1] * n[0]};
+                                float l2[3], w2[3];
+                                l2[0] = ((m[0] * rxn[0] + m[3] * rxn[1]) + m[6] * rxn[2]) * invI[0];
+                                l2[1] = ((m[1] * rxn[0] + m[4] * rxn[1]) + m[7] * rxn[2]) * invI[1];
+                                l2[2] = ((m[2] * rxn[0] + m[5] * rxn[1]) + m[8] * rxn[2]) * invI[2];
+                                w2[0] = (m[0] * l2[0] + m[1] * l2[1]) + m[2] * l2[2];
+                                w2[1] = (m[3] * l2[0] + m[4] * l2[1]) + m[5] * l2[2];
+                                w2[2] = (m[6] * l2[0] + m[7] * l2[1]) + m[8] * l2[2];
+                                const float K = invMass + ((rxn[0] * w2[0] + rxn[1] * w2[1]) + rxn[2] * w2[2]);
+                                const float j = need / K;
+                                for (int b = 0; b < 3; b++) {
+                                    lv[b] = lv[b] + (j * invMass) * n[b];
+                                    av[b] = av[b] + j * w2[b];
+                                }
+                            }
+                        }
+                }
+        }
+        for (int a = 0; a < 3; a++) center[a] = center[a] + lv[a] * dt;
         const float hd = 0.5f * dt;
         const float q0 = rot[0], q1 = rot[1], q2 = rot[2], q3 = rot[3];
         float nq[4];

@@ -612,8 +612,9 @@ ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMas
     free(mats);
 }
 
-/* rigid bodies: apply the particles' reaction, gravity, damping; integrate pose; keep the
- * body's world AABB inside [bmin,bmax] when bounded != 0 (inelastic clamp). */
+/* rigid bodies: apply the particles' reaction, gravity, damping; when bounded != 0 solve the
+ * corner contacts with the planes of [bmin,bmax]; integrate pose; a last positional clamp keeps
+ * the body's world AABB inside (whatever four iterations left over). */
 ORC_API void orc_integrate_bodies(OrcBox *boxes, int nboxes, const float *body_impulse, float dt,
                                   const float *gravity, int bounded, const float *bmin,
                                   const float *bmax)
@@ -634,8 +635,49 @@ ORC_API void orc_integrate_bodies(OrcBox *boxes, int nboxes, const float *body_i
             bx->linVel[a] = (bx->linVel[a] + body_impulse[6 * k + a] * bx->invMass +
                              gravity[a] * bx->gravityFactor * dt) * ld;
             bx->angVel[a] = (bx->angVel[a] + dw[a]) * ad;
-            bx->center[a] = bx->center[a] + bx->linVel[a] * dt;
         }
+        /* contacts of the box's eight corners with the six planes of [bmin,bmax] (the tank's
+         * walls), four passes of sequential impulses as the scene's four solver iterations
+         * (ConvertedSubScene.unity:235): speculative, inelastic (restitution max(0,0),
+         * :747-751, Wall.prefab), frictionless (geometric mean with the walls' 0, :742-746) */
+        if (bounded) {
+            const float *he = bx->halfExtents;
+            for (int it = 0; it < 4; it++)
+                for (int corner = 0; corner < 8; corner++) {
+                    float hl[3] = {(corner & 1) ? he[0] : -he[0], (corner & 2) ? he[1] : -he[1],
+                                   (corner & 4) ? he[2] : -he[2]};
+                    float r[3];
+                    mat_mul(m, hl, r);
+                    for (int a = 0; a < 3; a++)
+                        for (int side = 0; side < 2; side++) {
+                            float *lv = bx->linVel, *av = bx->angVel;
+                            float vc[3] = {lv[0] + (av[1] * r[2] - av[2] * r[1]),
+                                           lv[1] + (av[2] * r[0] - av[0] * r[2]),
+                                           lv[2] + (av[0] * r[1] - av[1] * r[0])};
+                            float sgn = side ? -1.0f : 1.0f;
+                            float pc = bx->center[a] + r[a];
+                            float gap = side ? bmax[a] - pc : pc - bmin[a];
+                            float need = -gap / dt - sgn * vc[a];
+                            if (need > 0.0f) {
+                                float n[3] = {0.0f, 0.0f, 0.0f};
+                                n[a] = sgn;
+                                float rxn[3] = {r[1] * n[2] - r[2] * n[1], r[2] * n[0] - r[0] * n[2],
+                                                r[0] * n[1] - r[1] * n[0]};
+                                float loc2[3], w2[3];
+                                mat_tmul(m, rxn, loc2);
+                                for (int b = 0; b < 3; b++) loc2[b] = loc2[b] * bx->invInertia[b];
+                                mat_mul(m, loc2, w2);
+                                float K = bx->invMass + ((rxn[0] * w2[0] + rxn[1] * w2[1]) + rxn[2] * w2[2]);
+                                float j = need / K;
+                                for (int b = 0; b < 3; b++) {
+                                    lv[b] = lv[b] + (j * bx->invMass) * n[b];
+                                    av[b] = av[b] + j * w2[b];
+                                }
+                            }
+                        }
+                }
+        }
+        for (int a = 0; a < 3; a++) bx->center[a] = bx->center[a] + bx->linVel[a] * dt;
         /* q += 0.5*dt*(w,0)*q, renormalised */
         float *q = bx->rot, *w = bx->angVel, hd = 0.5f * dt;
         float dq[4] = {hd * ((w[0] * q[3] + w[1] * q[2]) - w[2] * q[1]),

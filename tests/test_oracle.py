@@ -199,3 +199,34 @@ def test_oracle_matches_golden_sort_and_trajectory(oracle):
             np.testing.assert_array_equal(vel, t[f"vel{step}"])
             np.testing.assert_array_equal(boxes, t[f"boxes{step}"])
     assert np.isfinite(t["pos100"]).all() and np.isfinite(t["vel100"]).all()
+
+
+def test_body_wall_contact_is_a_corner_contact(oracle):
+    """row I, rigid bodies against the tank's planes (build-defined; Havok in the reference): a
+    box lying flat on the floor stays at rest on it, a tilted box that lands on one edge is turned
+    by the contact (an AABB clamp would only stop it) and no corner ends below the floor."""
+    from fluidsimulation_amd import scene
+    dt = float(scene.DT)
+    bounds = (np.float32([-10, 0, -10]), np.float32([10, 20, 10]))
+    flat = scene.dynamic_box((0.0, 1.0, 0.0), (0.5, 1.0, 0.5), 1000.0)
+    s = np.sin(0.3 / 2)
+    tilted = scene.dynamic_box((4.0, 1.3, 0.0), (0.5, 1.0, 0.5), 1000.0, rotation=(0, 0, s, np.cos(0.3 / 2)))
+    boxes = np.stack([flat, tilted]).astype(np.float32)
+    imp = np.zeros((2, 6), np.float32)
+    for _ in range(120):
+        boxes = oracle.integrate_bodies(boxes, imp, dt, bounds=bounds)
+    # flat: centre one half-height above the floor, no velocity, no rotation picked up
+    assert abs(boxes[0, 1] - 1.0) < 1e-3 and np.abs(boxes[0, 10:16]).max() < 1e-3
+    assert np.abs(boxes[0, 3:6]).max() < 1e-3   # (corner order of the sequential impulses: 3e-4 rad)
+    # tilted: it has turned about z (towards lying down or standing up), and every corner of
+    # both boxes is above the floor
+    assert abs(boxes[1, 5] - s) > 0.02
+    for b in boxes:
+        x, y, z, w = b[3:7]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        for c in range(8):
+            hl = b[7:10] * np.array([1 if c & 1 else -1, 1 if c & 2 else -1, 1 if c & 4 else -1])
+            assert (b[0:3] + R @ hl)[1] > -1e-3
+    assert np.isfinite(boxes).all()
