@@ -76,7 +76,12 @@
 #define NB_MTAB 64       // materials whose loop constants are cached in LDS
 #define NB_POOL_PIECE 8192 // 16-byte units of plan pool a plan workgroup takes at a time (128 KB)
 #define NB_LIST_PIECE 16   // block-list entries it takes at a time
+#ifndef NB_PLAN_WAVES
+#define NB_PLAN_WAVES 4 // waves per SIMD the plan kernel's register allocation must allow
+#endif
+#ifndef NB_PLAN_WGS_PER_CU
 #define NB_PLAN_WGS_PER_CU 16 // persistent plan workgroups (single waves) per CU
+#endif
 #ifndef NB_CHUNK
 #define NB_CHUNK 4 // blocks per work-queue request
 #endif
@@ -723,7 +728,7 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
 }
 
 // one wave per non-empty tile at a time
-__global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_plan(NbArgs A)
+__global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_PLAN_WAVES, NB_PLAN_WAVES))) void k_plan(NbArgs A)
 {
     __shared__ PlanShared sh;
     if (threadIdx.x == 0) sh.poolAt = sh.poolEnd = sh.listAt = sh.listEnd = 0;
@@ -1036,17 +1041,20 @@ void k_neighbors(NbArgs A)
         sh.mtab[i] = make_float4(m->negInvH2, m->negInvH, m->h2, m->thrF);
     }
     const uint32_t nblocks = min(A.ctl[NB_CTL_BLOCKS], (uint32_t)A.blockCap);
+    // blocks per request: NB_CHUNK when there is plenty of work, fewer when the whole list is only
+    // a few blocks per workgroup (small scenes: the work must spread over all the workgroups)
+    const uint32_t chunk = min((uint32_t)NB_CHUNK, max(1u, nblocks / (4u * gridDim.x)));
     uint32_t pending = 0;
-    if (tid == 0) pending = atomicAdd(&A.ctl[A.queue], (uint32_t)NB_CHUNK);
+    if (tid == 0) pending = atomicAdd(&A.ctl[A.queue], chunk);
     for (;;) {
         if (tid == 0) {
             sh.next = pending;
-            if (pending < nblocks) pending = atomicAdd(&A.ctl[A.queue], (uint32_t)NB_CHUNK);
+            if (pending < nblocks) pending = atomicAdd(&A.ctl[A.queue], chunk);
         }
         __syncthreads();
         const uint32_t first = sh.next;
         if (first >= nblocks) break;
-        const uint32_t n = min((uint32_t)NB_CHUNK, nblocks - first);
+        const uint32_t n = min(chunk, nblocks - first);
         if (tid < (int)n) sh.hdr[tid] = A.blockList[first + tid];
         __syncthreads();
         // every thread has read `next` before thread 0 can write it again: each block has barriers

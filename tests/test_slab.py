@@ -230,3 +230,38 @@ def test_native_rccl_exchange_world_of_one():
                 ctx.slab_comm_destroy()
     for a, b in zip(out[0], out[1]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_with_its_own_sizing(tmp_path):
+    """`python bench.py --gpus 2` exactly as the driver calls it (no launcher): it starts its two
+    ranks itself, sizes the exchange buffers and the slab capacity with its own formula and runs
+    40 steps of the C2 block pair while the fluid piles up against the far wall; over gloo, both
+    ranks on device 0 (the box has one GPU).  The line must say 2 GPUs and stay finite."""
+    env = dict(os.environ, SPH_BENCH_COMM="gloo", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C2",
+                        "--steps", "30", "--warmup", "10"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["finite"] is True
+    assert line["config"]["comm_backend"] == "gloo"
+    assert line["slab_rank0"]["sent_records_per_step"] > 0
+    assert line["value"] > 0 and "cpu_baseline" not in line
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_ranks_than_gpus_over_rccl():
+    """with the RCCL backend one GPU per rank is needed: `--gpus 2` on a one-GPU box fails loudly
+    instead of reporting n_gpus = 1"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than two GPUs")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "SPH_BENCH_COMM"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stdout + r.stderr)
