@@ -111,7 +111,9 @@ struct UnitDesc {
 typedef int4 BlockHdr;
 
 // control words shared by the plan and the neighbour kernels (SphCtx::tileCtl)
-enum { NB_CTL_TILES = 0, NB_CTL_BLOCKS, NB_CTL_GCELLS, NB_CTL_POOL, NB_CTL_ERROR, NB_CTL_QUEUE0 };
+// NB_CTL_ERROR sits behind the words that sph_map_table clears every step: an overflow in step k of
+// a long resident run is still there when the host next looks (sph_synchronize, sph_download)
+enum { NB_CTL_TILES = 0, NB_CTL_BLOCKS, NB_CTL_GCELLS, NB_CTL_POOL, NB_CTL_QUEUE0, NB_CTL_ERROR = 64 };
 
 // the 6x6x4 halo of a tile as the tables give it
 struct HaloTab {

@@ -59,7 +59,8 @@ struct MatKeyHash {
 
 } // namespace
 
-#define SPH_QUEUE_SLOTS 64 // tileCtl: [0] number of listed tiles, [1..63] work-queue counters
+#define SPH_QUEUE_SLOTS 64 // tileCtl: NB_CTL_* words and work-queue counters, cleared every step;
+                           // one more word behind them (SPH_CTL_ERROR_WORD) is the sticky error flag
 
 // ---- scratch of sph_sort_pairs_noalloc ------------------------------------------------------
 // The one entry point that allocates nothing keeps its scratch (one ping-pong (key, value) buffer,
@@ -800,8 +801,10 @@ static int check_plan_error(SphCtx *c)
 {
     if (!c->tileCtl.p) return SPH_OK;
     uint32_t e = 0;
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
     HIPCHK(c, hipMemcpyAsync(&e, c->tileCtl.p + NB_CTL_ERROR, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (e) HIPCHK(c, hipMemsetAsync(c->tileCtl.p + NB_CTL_ERROR, 0, 4, c->stream)); // reported once
     if (e) return fail(c, SPH_E_TOOLARGE, "neighbour plan overflow (flags %u): results of the last step are incomplete", e);
     return SPH_OK;
 }
@@ -1086,7 +1089,10 @@ int sph_map_table(SphCtx *c)
     int rc = ensure(c, c->table, (size_t)c->grid.cells);
     if (!rc) rc = ensure(c, c->ttable, (size_t)c->grid.tiles);
     if (!rc) rc = ensure(c, c->tileList, (size_t)c->grid.tiles);
-    if (!rc) rc = ensure(c, c->tileCtl, SPH_QUEUE_SLOTS, false);
+    if (!rc && !c->tileCtl.p) {
+        rc = ensure(c, c->tileCtl, SPH_QUEUE_SLOTS + 1, false);
+        if (!rc) HIPCHK(c, hipMemsetAsync(c->tileCtl.p, 0, (SPH_QUEUE_SLOTS + 1) * sizeof(uint32_t), c->stream));
+    }
     if (rc) return rc;
     rc = prepare_boundary(c);
     if (rc) return rc;
