@@ -40,6 +40,15 @@ def test_resident_steps_match_oracle(ctx, oracle, nsteps):
     assert_close(gpos, opos, rtol=rtol, what="position")
     assert_close(gvel, ovel, rtol=rtol, what="velocity")
     assert_close(ctx.get_colliders(), oboxes, rtol=rtol, what="bodies")
+    # element by element as well: coordinates with a floor of 1 % of h, velocity components with a
+    # floor of a fifth of the largest speed (a component is a sum of pair terms of the size of the
+    # largest one: below that floor it is cancellation, not signal)
+    # (one step; after ten the oracle itself moves by 6e-6 of the largest speed under a 1-ulp
+    # change of its input, profiles/r2_divergence_demo.txt: max-norm only)
+    assert_close_elementwise(gpos, opos, rtol=rtol, floor=0.01, what="position, element-wise")
+    if nsteps == 1:
+        assert_close_elementwise(gvel, ovel, rtol=rtol, floor=0.2 * float(np.abs(ovel).max()),
+                                 what="velocity, element-wise")
 
 
 def test_host_round_trip_equals_resident(ctx, oracle):
