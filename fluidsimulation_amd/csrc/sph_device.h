@@ -46,6 +46,8 @@ struct Mat {
 };
 
 // Box collider in the form the integrate kernel reads (row-major rotation, world = R*local)
+#define SPH_BOX_CHUNK 32 // boxes per broadphase chunk (consecutive indices)
+
 struct DevBox {
     float c[3];
     float R[9];

@@ -195,6 +195,8 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
     const float *__restrict__ rho, const uint32_t *__restrict__ mat,
     const Mat *__restrict__ mats, int n, float dt, const DevBox *__restrict__ boxes, int nboxes,
     float particleRestitution, float *__restrict__ bodyImpulse,
+    const float4 *__restrict__ boxAabb /* 2 per box: min, max */,
+    const float4 *__restrict__ chunkAabb /* 2 per chunk of SPH_BOX_CHUNK boxes */,
     const uint32_t *__restrict__ slabFlags /* slab mode: ids with the ghost bit, else nullptr */,
     uint32_t *__restrict__ nextKeys /* nullable: the next step's cell keys (saves k_keys) */,
     GridDesc grid)
@@ -247,11 +249,22 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
             }
         };
         if (nboxes > 0) wave_bounds();
+        auto misses = [&](const float4 lo, const float4 hi) { // wave-uniform (scalar operands)
+            return wmax[0] < lo.x || wmin[0] > hi.x || wmax[1] < lo.y || wmin[1] > hi.y ||
+                   wmax[2] < lo.z || wmin[2] > hi.z;
+        };
+        // two levels, in index order (the order of the boxes is part of the result): chunks of
+        // SPH_BOX_CHUNK consecutive boxes by their joint bounds, then the boxes of a chunk
         for (int k = 0; k < nboxes; k++) {
+            if ((k & (SPH_BOX_CHUNK - 1)) == 0) {
+                const int ch = k / SPH_BOX_CHUNK;
+                if (misses(chunkAabb[2 * ch], chunkAabb[2 * ch + 1])) {
+                    k += SPH_BOX_CHUNK - 1;
+                    continue;
+                }
+            }
+            if (misses(boxAabb[2 * k], boxAabb[2 * k + 1])) continue;
             const DevBox &bx = boxes[k];
-            if (wmax[0] < bx.amin[0] || wmin[0] > bx.amax[0] || wmax[1] < bx.amin[1] ||
-                wmin[1] > bx.amax[1] || wmax[2] < bx.amin[2] || wmin[2] > bx.amax[2])
-                continue; // wave-uniform
             float imp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             bool pushed = false, touched = false;
             if (live) {
@@ -373,7 +386,7 @@ __device__ __forceinline__ void quat_to_mat(const float *q, float *m)
 }
 
 __global__ void k_bodies(float *__restrict__ state, DevBox *__restrict__ dev,
-                         float *__restrict__ bodyImpulse, int nboxes, int integrate, float dt,
+                         float4 *__restrict__ boxAabb, float *__restrict__ bodyImpulse, int nboxes, int integrate, float dt,
                          float gx, float gy, float gz, int bounded, float bminx, float bminy,
                          float bminz, float bmaxx, float bmaxy, float bmaxz)
 {
@@ -491,5 +504,24 @@ __global__ void k_bodies(float *__restrict__ state, DevBox *__restrict__ dev,
         d.amax[a] = center[a] + ext;
     }
     dev[k] = d;
+    boxAabb[2 * k] = make_float4(d.amin[0], d.amin[1], d.amin[2], 0.f);
+    boxAabb[2 * k + 1] = make_float4(d.amax[0], d.amax[1], d.amax[2], 0.f);
     for (int a = 0; a < 6; a++) bodyImpulse[6 * k + a] = 0.f;
+}
+
+// joint bounds of every SPH_BOX_CHUNK consecutive boxes (broadphase of k_apply_integrate)
+__global__ void k_box_chunks(const float4 *__restrict__ boxAabb, int nboxes,
+                             float4 *__restrict__ chunkAabb)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k0 = ch * SPH_BOX_CHUNK;
+    if (k0 >= nboxes) return;
+    float4 lo = boxAabb[2 * k0], hi = boxAabb[2 * k0 + 1];
+    for (int k = k0 + 1; k < min(k0 + SPH_BOX_CHUNK, nboxes); k++) {
+        const float4 a = boxAabb[2 * k], b = boxAabb[2 * k + 1];
+        lo.x = fminf(lo.x, a.x); lo.y = fminf(lo.y, a.y); lo.z = fminf(lo.z, a.z);
+        hi.x = fmaxf(hi.x, b.x); hi.y = fmaxf(hi.y, b.y); hi.z = fmaxf(hi.z, b.z);
+    }
+    chunkAabb[2 * ch] = lo;
+    chunkAabb[2 * ch + 1] = hi;
 }

@@ -153,6 +153,7 @@ struct SphCtx {
     bool anyDynamicBox = false;
     DevBuf<float> boxState;
     DevBuf<DevBox> devBoxes;
+    DevBuf<float4> boxAabb, chunkAabb; // world bounds per box / per SPH_BOX_CHUNK boxes
     DevBuf<float> bodyImpulse;
 
     // sort scratch
@@ -759,7 +760,7 @@ int sph_destroy(SphCtx *c)
     release(c->dmats); release(c->table); release(c->btable); release(c->ttable); release(c->tileList); release(c->tileCtl); release(c->blockList); release(c->gcellList); release(c->pool);
     release(c->bpos3); release(c->bpar3); release(c->bposmIn); release(c->bposm);
     release(c->bkeysA); release(c->bkeysB); release(c->bvalsA); release(c->bvalsB);
-    release(c->boxState); release(c->devBoxes); release(c->bodyImpulse);
+    release(c->boxState); release(c->devBoxes); release(c->bodyImpulse); release(c->boxAabb); release(c->chunkAabb);
     release(c->hist); release(c->rowTotal); release(c->partial);
     for (const EventPair &ep : c->pending) {
         (void)hipEventDestroy(ep.a);
@@ -875,12 +876,16 @@ int sph_set_colliders(SphCtx *c, const SphBox *boxes, int32_t K)
     int rc = ensure(c, c->boxState, (size_t)25 * K);
     if (!rc) rc = ensure(c, c->devBoxes, (size_t)K);
     if (!rc) rc = ensure(c, c->bodyImpulse, (size_t)6 * K);
+    if (!rc) rc = ensure(c, c->boxAabb, (size_t)2 * K);
+    if (!rc) rc = ensure(c, c->chunkAabb, (size_t)2 * blocks_for(K, SPH_BOX_CHUNK));
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->boxState.p, boxes, sizeof(SphBox) * (size_t)K,
                              hipMemcpyHostToDevice, c->stream));
-    k_bodies<<<blocks_for(K, 64), 64, 0, c->stream>>>(c->boxState.p, c->devBoxes.p,
+    k_bodies<<<blocks_for(K, 64), 64, 0, c->stream>>>(c->boxState.p, c->devBoxes.p, c->boxAabb.p,
                                                       c->bodyImpulse.p, K, 0, 0.f, 0.f, 0.f, 0.f,
                                                       0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+    k_box_chunks<<<blocks_for(blocks_for(K, SPH_BOX_CHUNK), 64), 64, 0, c->stream>>>(
+        c->boxAabb.p, K, c->chunkAabb.p);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPH_OK;
 }
@@ -1280,6 +1285,7 @@ static int launch_apply_integrate(SphCtx *c, const SphParams *p, bool apply, boo
     k_apply_integrate<A, I><<<nb, 256, 0, c->stream>>>(                                          \
         c->posm[cur].p, c->velq[cur].p, c->force.p, c->rho.p, c->mat[cur].p, c->dmats.p, N,      \
         p->dt, c->devBoxes.p, c->nboxes, p->particleRestitution, c->bodyImpulse.p,               \
+        c->boxAabb.p, c->chunkAabb.p,                                                            \
         c->slab ? c->oid[cur].p : nullptr, nextKeys ? c->keysA.p : nullptr, c->grid)
     if (apply && integrate) LAUNCH_AI(true, true);
     else if (apply) LAUNCH_AI(true, false);
@@ -1294,9 +1300,12 @@ static int launch_bodies(SphCtx *c, const SphParams *p)
     if (c->nboxes <= 0) return SPH_OK;
     StageTimer t(c, SPH_T_BODIES);
     k_bodies<<<blocks_for(c->nboxes, 64), 64, 0, c->stream>>>(
-        c->boxState.p, c->devBoxes.p, c->bodyImpulse.p, c->nboxes, 1, p->dt, p->gravity[0],
-        p->gravity[1], p->gravity[2], p->boundBodies, p->bodyMin[0], p->bodyMin[1], p->bodyMin[2],
-        p->bodyMax[0], p->bodyMax[1], p->bodyMax[2]);
+        c->boxState.p, c->devBoxes.p, c->boxAabb.p, c->bodyImpulse.p, c->nboxes, 1, p->dt,
+        p->gravity[0], p->gravity[1], p->gravity[2], p->boundBodies, p->bodyMin[0], p->bodyMin[1],
+        p->bodyMin[2], p->bodyMax[0], p->bodyMax[1], p->bodyMax[2]);
+    if (c->anyDynamicBox) // (static boxes keep the chunk bounds of sph_set_colliders)
+        k_box_chunks<<<blocks_for(blocks_for(c->nboxes, SPH_BOX_CHUNK), 64), 64, 0, c->stream>>>(
+            c->boxAabb.p, c->nboxes, c->chunkAabb.p);
     HIPCHK(c, hipGetLastError());
     return SPH_OK;
 }
