@@ -1334,6 +1334,43 @@ int sph_integrate(SphCtx *c, const SphParams *p)
     return launch_bodies(c, p);
 }
 
+// one step of the resident loop: keysReady = the previous step's integrate kernel has written
+// this step's cell keys; writeNextKeys = this step's does the same for the next one
+static int resident_step(SphCtx *c, const SphParams *p, bool keysReady, bool writeNextKeys)
+{
+    int rc;
+    if (keysReady) {
+        if ((rc = sync_params(c, p))) return rc;
+        c->haveKeys = true;
+    } else if ((rc = sph_hash_position(c, p))) {
+        return rc;
+    }
+    if ((rc = sph_radix_sort(c))) return rc;
+    if ((rc = sph_map_table(c))) return rc;
+    // the plan needs the tables only: it runs on the second stream beside the reorder pass
+    // (one is bound by latency, the other by HBM)
+    const bool side = c->stream2 != nullptr;
+    if (side) {
+        HIPCHK(c, hipEventRecord(c->evTable, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evTable, 0));
+        if ((rc = ensure_plan(c, p, c->stream2))) return rc;
+        HIPCHK(c, hipEventRecord(c->evPlan, c->stream2));
+    }
+    if ((rc = sph_reorder(c))) return rc;
+    if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evPlan, 0));
+    if ((rc = sph_compute_density_and_pressure(c, p))) return rc;
+    if ((rc = sph_compute_force(c, p))) return rc;
+    {
+        StageTimer t(c, SPH_T_INTEGRATE);
+        if ((rc = launch_apply_integrate(c, p, true, true, writeNextKeys))) return rc;
+    }
+    c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
+    c->haveDensity = c->haveForce = false;
+    if ((rc = launch_bodies(c, p))) return rc;
+    c->tm.steps++;
+    return SPH_OK;
+}
+
 int sph_step_resident(SphCtx *c, const SphParams *p, int32_t nsteps)
 {
     int rc = check_params(c, p);
@@ -1349,36 +1386,9 @@ int sph_step_resident(SphCtx *c, const SphParams *p, int32_t nsteps)
     bool keysReady = false;
     for (int s = 0; s < nsteps; s++) {
         if (c->timing) drain_timings(c);
-        if (keysReady) {
-            if ((rc = sync_params(c, p))) return rc;
-            c->haveKeys = true;
-        } else if ((rc = sph_hash_position(c, p))) {
-            return rc;
-        }
-        if ((rc = sph_radix_sort(c))) return rc;
-        if ((rc = sph_map_table(c))) return rc;
-        // the plan needs the tables only: it runs on the second stream beside the reorder pass
-        // (one is bound by latency, the other by HBM)
-        const bool side = c->stream2 != nullptr;
-        if (side) {
-            HIPCHK(c, hipEventRecord(c->evTable, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evTable, 0));
-            if ((rc = ensure_plan(c, p, c->stream2))) return rc;
-            HIPCHK(c, hipEventRecord(c->evPlan, c->stream2));
-        }
-        if ((rc = sph_reorder(c))) return rc;
-        if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evPlan, 0));
-        if ((rc = sph_compute_density_and_pressure(c, p))) return rc;
-        if ((rc = sph_compute_force(c, p))) return rc;
-        keysReady = fuse && s + 1 < nsteps;
-        {
-            StageTimer t(c, SPH_T_INTEGRATE);
-            if ((rc = launch_apply_integrate(c, p, true, true, keysReady))) return rc;
-        }
-        c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
-        c->haveDensity = c->haveForce = false;
-        if ((rc = launch_bodies(c, p))) return rc;
-        c->tm.steps++;
+        const bool next = fuse && s + 1 < nsteps;
+        if ((rc = resident_step(c, p, keysReady, next))) return rc;
+        keysReady = next;
     }
     return SPH_OK;
 }
