@@ -7,7 +7,7 @@
 //
 // Mapping (DESIGN.md "neighbour kernels").  The sort key groups particles by TILE of 4x4x2 cells
 // (sph_device.h).  A tile is worked through in BLOCKS: the whole tile when its halo (block + one
-// cell on every side) fits the LDS image, else halves (4x4x1, 4x2x1, 2x2x1), else single cells
+// cell on every side) fits the LDS image, else parts (4x2x2, 4x2x1, 2x2x1), else single cells
 // (the fluid compresses several-fold at the bottom of a deep tank), else -- for a cell whose
 // 27-cell neighbourhood still overflows -- a walk straight from global memory.
 //
@@ -751,37 +751,28 @@ __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_
             tile_lookup_load(hr, tile, A);
             if (ti + 2 * gridDim.x < ntiles) tileNext = (int)A.tileList[ti + 2 * gridDim.x];
         }
-        // The largest block whose 27-cell halo fits the LDS image: the whole tile, then halves
-        // (4x4x1, 4x2x1, 2x2x1) down to single cells, then the global-memory path.  The 32 cells
-        // are numbered so that every block is an aligned run: n = z*16 + (y/2)*8 + (x/2)*4 +
-        // (y&1)*2 + (x&1).
+        // The largest blocks whose 27-cell halo fits the LDS image: the whole tile (halo 144
+        // cells for 32), else per y-half a 4x2x2 block (96 for 16), else per layer 4x2x1 (72 for
+        // 8), 2x2x1 (48 for 4), single cells (27 for 1), else the global-memory path.  Blocks stay
+        // long in x, the direction of the row windows.  One instantiation per shape.
         if (plan_block<SPH_TX, SPH_TY, SPH_TZ>(sh, A, tileCur, 0, 0, 0)) continue;
-        int cursor = 0, size = SPH_TCELLS / 2;
-        while (cursor < SPH_TCELLS) {
-            const int bx = ((cursor >> 2) & 1) * 2 + (cursor & 1), by = ((cursor >> 3) & 1) * 2 + ((cursor >> 1) & 1),
-                      bz = cursor >> 4;
-            bool ok; // one instantiation per shape: the shape is a compile-time constant in each
-            switch (size) {
-            case 16: ok = plan_block<4, 4, 1>(sh, A, tileCur, bx, by, bz); break;
-            case 8: ok = plan_block<4, 2, 1>(sh, A, tileCur, bx, by, bz); break;
-            case 4: ok = plan_block<2, 2, 1>(sh, A, tileCur, bx, by, bz); break;
-            default: ok = plan_block<1, 1, 1>(sh, A, tileCur, bx, by, bz); break;
-            }
-            if (ok) {
-                cursor += size;
-            } else if (size > 1) {
-                size = size == 4 ? 1 : size >> 1;
-                continue;
-            } else {
-                if (threadIdx.x == 0 && sh.h.fc[tile_halo_index(bx + 1, by + 1, bz + 1)] > 0) {
-                    const uint32_t idx = atomicAdd(&A.ctl[NB_CTL_GCELLS], 1u);
-                    if (idx < (uint32_t)A.gcellCap) A.gcellList[idx] = make_int2(tileCur, bx | (by << 8) | (bz << 16));
-                    else atomicOr(&A.ctl[NB_CTL_ERROR], 2u);
+        for (int yh = 0; yh < 2; yh++) {
+            if (plan_block<4, 2, 2>(sh, A, tileCur, 0, 2 * yh, 0)) continue;
+            for (int z = 0; z < 2; z++) {
+                if (plan_block<4, 2, 1>(sh, A, tileCur, 0, 2 * yh, z)) continue;
+                for (int xh = 0; xh < 2; xh++) {
+                    if (plan_block<2, 2, 1>(sh, A, tileCur, 2 * xh, 2 * yh, z)) continue;
+                    for (int q = 0; q < 4; q++) {
+                        const int bx = 2 * xh + (q & 1), by = 2 * yh + (q >> 1);
+                        if (plan_block<1, 1, 1>(sh, A, tileCur, bx, by, z)) continue;
+                        if (threadIdx.x == 0 && sh.h.fc[tile_halo_index(bx + 1, by + 1, z + 1)] > 0) {
+                            const uint32_t idx = atomicAdd(&A.ctl[NB_CTL_GCELLS], 1u);
+                            if (idx < (uint32_t)A.gcellCap) A.gcellList[idx] = make_int2(tileCur, bx | (by << 8) | (z << 16));
+                            else atomicOr(&A.ctl[NB_CTL_ERROR], 2u);
+                        }
+                    }
                 }
-                cursor += 1;
             }
-            const int low = cursor & -cursor; // largest aligned block at the new cursor
-            size = low >= 16 ? 16 : low >= 8 ? 8 : low >= 4 ? 4 : 1;
         }
         wave_lds_fence(); // sh.h is rewritten by the next tile
     }

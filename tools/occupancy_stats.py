@@ -44,7 +44,7 @@ for chunk in range(0, nsteps, 50):
     live = own > 0
     h = halo[live]
     print(f"   tiles with fluid {live.sum()}, halo records mean {h.mean():.0f} p90 {np.percentile(h, 90):.0f} "
-          f"p99 {np.percentile(h, 99):.0f} max {h.max()}; > 2048: {np.mean(h > 2048):.3f}, > 1792: "
+          f"p99 {np.percentile(h, 99):.0f} max {h.max()}; > 1184: {np.mean(h > 1184):.3f}, > 1792: "
           f"{np.mean(h > 1792):.3f}; own > 512: {np.mean(own[live] > 512):.4f}")
     t = ctx.timings(); ctx.reset_timings()
     print("   stage ms/step:", {k: round(v / max(t['steps'], 1), 3) for k, v in t['ms'].items()})
