@@ -525,3 +525,36 @@ __global__ void k_box_chunks(const float4 *__restrict__ boxAabb, int nboxes,
     chunkAabb[2 * ch] = lo;
     chunkAabb[2 * ch + 1] = hi;
 }
+
+// ---- density field for rendering (the reference's open roadmap item "fluid texture",
+// readme_zh.md:303): rho(x) = sum_j m_j W_poly6(|x - x_j|, h_j) over the fluid particles of the 27
+// cells around x, at the nodes of a regular grid, x fastest.  One thread per node; the particles
+// are the resident sorted records, found through the cell table.
+__global__ __launch_bounds__(256) void k_sample_density(
+    const float4 *__restrict__ posm, const uint32_t *__restrict__ mat, const Mat *__restrict__ mats,
+    const int2 *__restrict__ table, GridDesc g, float ox, float oy, float oz, float spacing, int nx,
+    int ny, int nz, float *__restrict__ field)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)nx * ny * nz) return;
+    const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / ((long)nx * ny));
+    const float x = ox + (float)ix * spacing, y = oy + (float)iy * spacing, z = oz + (float)iz * spacing;
+    const int cx = quantize1(x, g.cellSize), cy = quantize1(y, g.cellSize), cz = quantize1(z, g.cellSize);
+    float sum = 0.f;
+    for (int dx = -1; dx <= 1; dx++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dz = -1; dz <= 1; dz++) {
+                const int2 r = table[dense_key(cx + dx, cy + dy, cz + dz, g)];
+                for (int j = r.x; j < r.y; j++) {
+                    const float4 p = posm[j];
+                    const Mat &m = mats[mat[j]];
+                    const float ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
+                    const float d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                    if (d2 < m.h2) {
+                        const float w = m.h2 - d2;
+                        sum += m.poly6 * ((w * w) * w);
+                    }
+                }
+            }
+    field[i] = sum;
+}

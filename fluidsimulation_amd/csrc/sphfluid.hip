@@ -1529,6 +1529,34 @@ int sph_read(SphCtx *c, int32_t buffer, void *out, size_t bytes)
     return SPH_OK;
 }
 
+int sph_sample_density(SphCtx *c, const SphParams *p, const float origin[3], float spacing,
+                       const int32_t dims[3], float *field_out)
+{
+    int rc = sync_params(c, p);
+    if (rc) return rc;
+    if (!origin || !dims || !field_out || !(spacing > 0.f) || dims[0] <= 0 || dims[1] <= 0 || dims[2] <= 0)
+        return fail(c, SPH_E_INVALID, "sph_sample_density: bad grid");
+    const long long nodes = (long long)dims[0] * dims[1] * dims[2];
+    if (nodes > (1ll << 31) - 1) return fail(c, SPH_E_TOOLARGE, "sph_sample_density: more than 2^31 nodes");
+    if (c->slab) return fail(c, SPH_E_INVALID, "sph_sample_density is not available in slab mode");
+    // the table of the resident order (after a step the particles have moved: sort again)
+    if (!c->ordered) {
+        if ((rc = sph_hash_position(c, p))) return rc;
+        if ((rc = sph_radix_sort(c))) return rc;
+        if ((rc = sph_map_table(c))) return rc;
+        if ((rc = sph_reorder(c))) return rc;
+    }
+    if ((rc = ensure(c, c->io1, (size_t)std::max<long long>(nodes, c->n)))) return rc;
+    const int cur = c->cur;
+    k_sample_density<<<blocks_for((long)nodes, 256), 256, 0, c->stream>>>(
+        c->posm[cur].p, c->mat[cur].p, c->dmats.p, c->table.p, c->grid, origin[0], origin[1], origin[2],
+        spacing, dims[0], dims[1], dims[2], c->io1.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(field_out, c->io1.p, sizeof(float) * (size_t)nodes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
 int sph_find_bounds(SphCtx *c, float gridSize, float mn[3], float mx[3])
 {
     if (!c || !mn || !mx) return SPH_E_INVALID;

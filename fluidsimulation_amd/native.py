@@ -37,7 +37,7 @@ EXPORTS = [
     "sph_hash_position", "sph_radix_sort", "sph_map_table", "sph_reorder",
     "sph_compute_density_and_pressure", "sph_compute_force", "sph_apply_force", "sph_integrate",
     "sph_step_resident", "sph_step", "sph_step_compat", "sph_read", "sph_find_bounds",
-    "sph_sort_pairs", "sph_sort_pairs_noalloc", "sph_get_timings", "sph_reset_timings",
+    "sph_sample_density", "sph_sort_pairs", "sph_sort_pairs_noalloc", "sph_get_timings", "sph_reset_timings",
     "sph_slab_upload", "sph_slab_pack", "sph_slab_import", "sph_slab_counts", "sph_slab_download",
     "sph_slab_step_particles", "sph_slab_get_impulses", "sph_slab_step_bodies",
     "sph_slab_comm_unique_id", "sph_slab_comm_init", "sph_slab_exchange", "sph_slab_comm_destroy",
@@ -118,6 +118,7 @@ def load():
     lib.sph_step_compat.argtypes = [vp, C.POINTER(SphParams), vp, vp, vp, vp, i32, vp, vp]
     lib.sph_read.argtypes = [vp, i32, vp, C.c_size_t]
     lib.sph_find_bounds.argtypes = [vp, f32, vp, vp]
+    lib.sph_sample_density.argtypes = [vp, C.POINTER(SphParams), vp, f32, vp, vp]
     lib.sph_sort_pairs.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.sph_sort_pairs_noalloc.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.sph_get_timings.argtypes = [vp, C.POINTER(SphTimings)]
@@ -307,6 +308,14 @@ class Context:
         self._chk(self.lib.sph_step(self.h, C.byref(p), _ptr(pos), _ptr(vel), _ptr(inv_mass),
                                     _ptr(params), n, _ptr(dens), _ptr(forces)))
         return pos, vel, dens, forces
+
+    def sample_density(self, p, origin, spacing, dims):
+        """density field rho(x) on a regular grid (z, y, x order of the returned array)"""
+        o = np.ascontiguousarray(origin, np.float32)
+        d = np.ascontiguousarray(dims, np.int32)
+        out = np.empty((int(d[2]), int(d[1]), int(d[0])), np.float32)
+        self._chk(self.lib.sph_sample_density(self.h, C.byref(p), _ptr(o), float(spacing), _ptr(d), _ptr(out)))
+        return out
 
     def step_inplace(self, p, pos, vel, inv_mass, params, dens=None, forces=None):
         """sph_step on the caller's own arrays, as the C# host calls it: pos / vel are read and

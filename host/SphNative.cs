@@ -141,6 +141,7 @@ public static unsafe class SphNative
     // ---- parity / inspection
     [DllImport(Lib)] public static extern int sph_read(IntPtr ctx, int buffer, void* dst, UIntPtr bytes);
     [DllImport(Lib)] public static extern int sph_find_bounds(IntPtr ctx, float gridSize, float* mnOut, float* mxOut);
+    [DllImport(Lib)] public static extern int sph_sample_density(IntPtr ctx, SphParams* p, float* origin, float spacing, int* dims, float* fieldOut);
     [DllImport(Lib)] public static extern int sph_sort_pairs(IntPtr ctx, uint* keys, int n, int keyBits, uint* permOut, uint* sortedKeysOut);
     [DllImport(Lib)] public static extern int sph_sort_pairs_noalloc(IntPtr ctx, void* keysDev, int n, int keyBits, void* permOutDev, void* sortedKeysOutDev);
     [DllImport(Lib)] public static extern int sph_get_timings(IntPtr ctx, SphTimings* timingsOut);

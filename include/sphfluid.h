@@ -231,6 +231,14 @@ SPH_API int sph_step_compat(SphCtx *ctx, const SphParams *p, const float *pos, c
 SPH_API int sph_read(SphCtx *ctx, int32_t buffer, void *out, size_t bytes);
 /* FindBoundsJob's snapped AABB (FluidSPHUtils.cs:57-93) of the resident fluid + boundary */
 SPH_API int sph_find_bounds(SphCtx *ctx, float gridSize, float mn_out[3], float mx_out[3]);
+/* Density field for rendering (the reference's open roadmap item "compute a fluid
+ * texture so that the particles render as a liquid", readme_zh.md:303 -- it has no counterpart in the
+ * reference's code): rho(x) = sum over fluid particles j of m_j * 315/(64 pi h_j^9) (h_j^2 - |x-x_j|^2)^3
+ * at the nodes origin + (ix, iy, iz) * spacing of a grid of dims nodes, written x fastest into the
+ * host array field_out (dims[0]*dims[1]*dims[2] floats).  Sorts the resident state first if it has
+ * moved since the last sort.  Support radii must not exceed the cell size (27-cell search). */
+SPH_API int sph_sample_density(SphCtx *ctx, const SphParams *p, const float origin[3], float spacing,
+                               const int32_t dims[3], float *field_out);
 /* the radix sort on its own: stable ascending sort of ids 0..n-1 by the low key_bits of keys */
 SPH_API int sph_sort_pairs(SphCtx *ctx, const uint32_t *keys, int32_t n, int32_t key_bits,
                            uint32_t *perm_out, uint32_t *sorted_keys_out);

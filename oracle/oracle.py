@@ -212,5 +212,17 @@ def integrate_bodies(boxes, impulses, dt, gravity=(0.0, -9.81, 0.0), bounds=None
     return boxes
 
 
+def sample_density(pos, inv_mass, params, origin, spacing, dims, rate=4.0):
+    pos = _f32(pos).reshape(-1, 3)
+    inv_mass = _f32(inv_mass)
+    params = _f32(params).reshape(-1, 4)
+    o = _f32(origin)
+    d = np.ascontiguousarray(dims, np.int32)
+    out = np.empty((int(d[2]), int(d[1]), int(d[0])), np.float32)
+    lib().orc_sample_density(_p(pos), _p(inv_mass), _p(params), C.c_int(len(pos)), C.c_float(rate),
+                             _p(o), C.c_float(spacing), _p(d), _p(out))
+    return out
+
+
 def max_threads():
     return int(lib().orc_max_threads())

@@ -707,6 +707,39 @@ ORC_API void orc_integrate_bodies(OrcBox *boxes, int nboxes, const float *body_i
     }
 }
 
+/* density field for rendering (no counterpart in the reference's code; its roadmap item
+ * readme_zh.md:303): rho(x) = sum_j m_j 315/(64 pi h_j^9) (h_j^2 - d^2)^3 over ALL fluid particles
+ * with d^2 < h_j^2, brute force, at the nodes origin + (ix,iy,iz)*spacing, x fastest. */
+ORC_API void orc_sample_density(const float *pos, const float *inv_mass, const float *params, int n,
+                                float rate, const float *origin, float spacing, const int *dims,
+                                float *field)
+{
+    const float PI = 3.14159274f;
+    long nodes = (long)dims[0] * dims[1] * dims[2];
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < nodes; i++) {
+        int ix = (int)(i % dims[0]), iy = (int)((i / dims[0]) % dims[1]),
+            iz = (int)(i / ((long)dims[0] * dims[1]));
+        float x = origin[0] + (float)ix * spacing, y = origin[1] + (float)iy * spacing,
+              z = origin[2] + (float)iz * spacing;
+        float sum = 0.0f;
+        for (int j = 0; j < n; j++) {
+            float h = params[4 * j] * rate, h2 = h * h;
+            float dx = x - pos[3 * j], dy = y - pos[3 * j + 1], dz = z - pos[3 * j + 2];
+            float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < h2) {
+                float mass = 1.0f / inv_mass[j];
+                volatile float h9 = powf(h, 9.0f);
+                volatile float den = 64.0f * PI * h9;
+                float c = mass * 315.0f / den;
+                float w = h2 - d2;
+                sum += c * ((w * w) * w);
+            }
+        }
+        field[i] = sum;
+    }
+}
+
 ORC_API int orc_max_threads(void)
 {
 #ifdef _OPENMP

@@ -230,3 +230,14 @@ def test_body_wall_contact_is_a_corner_contact(oracle):
             hl = b[7:10] * np.array([1 if c & 1 else -1, 1 if c & 2 else -1, 1 if c & 4 else -1])
             assert (b[0:3] + R @ hl)[1] > -1e-3
     assert np.isfinite(boxes).all()
+
+
+def test_density_field_at_a_lattice_site_is_the_rest_lattice_density(oracle):
+    """the field sampler at the position of an interior particle of the rest lattice
+    equals the particle density SURVEY section 4 derives (1009.775), and is 0 far from the fluid"""
+    from fluidsimulation_amd import scene
+    sc = scene.demo_scene()
+    centre = sc.pos[np.argmin(np.linalg.norm(sc.pos - sc.pos.mean(axis=0), axis=1))]
+    f = oracle.sample_density(sc.pos, sc.inv_mass, sc.params, centre, 100.0, (2, 1, 1))
+    assert abs(float(f[0, 0, 0]) - 1009.775) < 0.01
+    assert float(f[0, 0, 1]) == 0.0
