@@ -62,7 +62,7 @@
 #endif
 #define NB_MAXWAVES 8
 #ifndef NB_DG
-#define NB_DG 4 // slots per loop iteration (records in flight per lane), density
+#define NB_DG 8 // slots per loop iteration (records in flight per lane), density (8: -2..4 % against 4)
 #endif
 #ifndef NB_FG
 #define NB_FG 2 // same, force
@@ -959,6 +959,10 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
                 if constexpr (G == 4) {
                     const uint4 q = *(const uint4 *)sp;
                     e[0] = q.x; e[1] = q.y; e[2] = q.z; e[3] = q.w;
+                } else if constexpr (G == 8) {
+                    const uint4 q0 = *(const uint4 *)sp, q1 = *(const uint4 *)(sp + 16);
+                    e[0] = q0.x; e[1] = q0.y; e[2] = q0.z; e[3] = q0.w;
+                    e[4] = q1.x; e[5] = q1.y; e[6] = q1.z; e[7] = q1.w;
                 } else if constexpr (G == 2) {
                     const uint2 q = *(const uint2 *)sp;
                     e[0] = q.x; e[1] = q.y;
