@@ -386,7 +386,8 @@ __device__ __forceinline__ void quat_to_mat(const float *q, float *m)
 }
 
 __global__ void k_bodies(float *__restrict__ state, DevBox *__restrict__ dev,
-                         float4 *__restrict__ boxAabb, float *__restrict__ bodyImpulse, int nboxes, int integrate, float dt,
+                         float4 *__restrict__ boxAabb, float *__restrict__ bodyImpulse,
+                         const float *__restrict__ velIn, int nboxes, int integrate, float dt,
                          float gx, float gy, float gz, int bounded, float bminx, float bminy,
                          float bminz, float bmaxx, float bmaxy, float bmaxz)
 {
@@ -398,11 +399,19 @@ __global__ void k_bodies(float *__restrict__ state, DevBox *__restrict__ dev,
     const bool dynamic = invMass != 0.f || invI[0] != 0.f || invI[1] != 0.f || invI[2] != 0.f;
     float m[9];
     quat_to_mat(rot, m);
-    if (integrate && dynamic) {
+    // integrate: 0 = refresh the device view only, 1 = the whole update, 2 = velocities only
+    // (impulses, gravity, damping: before the box-box contact passes), 3 = the rest (velocities
+    // from velIn, tank contacts, pose)
+    const bool doVel = integrate == 1 || integrate == 2, doRest = integrate == 1 || integrate == 3;
+    if (integrate == 3 && velIn && dynamic)
+        for (int a = 0; a < 3; a++) {
+            lv[a] = velIn[6 * k + a];
+            av[a] = velIn[6 * k + 3 + a];
+        }
+    if (doVel && dynamic) {
         const float *imp = bodyImpulse + 6 * k;
-        const float g[3] = {gx, gy, gz}, bmin[3] = {bminx, bminy, bminz},
-                    bmax[3] = {bmaxx, bmaxy, bmaxz};
         float loc[3], dw[3];
+        const float g[3] = {gx, gy, gz};
         loc[0] = ((m[0] * imp[3] + m[3] * imp[4]) + m[6] * imp[5]) * invI[0];
         loc[1] = ((m[1] * imp[3] + m[4] * imp[4]) + m[7] * imp[5]) * invI[1];
         loc[2] = ((m[2] * imp[3] + m[5] * imp[4]) + m[8] * imp[5]) * invI[2];
@@ -415,6 +424,9 @@ __global__ void k_bodies(float *__restrict__ state, DevBox *__restrict__ dev,
             lv[a] = (lv[a] + imp[a] * invMass + g[a] * gfac * dt) * ld;
             av[a] = (av[a] + dw[a]) * ad;
         }
+    }
+    if (doRest && dynamic) {
+        const float bmin[3] = {bminx, bminy, bminz}, bmax[3] = {bmaxx, bmaxy, bmaxz};
         // contacts of the box's eight corners with the six planes of [bmin,bmax] (the tank's
         // walls): four passes of sequential impulses (ConvertedSubScene.unity:235), speculative,
         // inelastic, frictionless (geometric mean with the walls' friction 0, :742-746)
@@ -557,4 +569,186 @@ __global__ __launch_bounds__(256) void k_sample_density(
                 }
             }
     field[i] = sum;
+}
+
+// ---- contacts between boxes (row I, build-defined; Unity Physics / Havok in the reference) ------
+// A contact is a corner of box X inside box Y: normal = Y's nearest face (out of Y), depth = the
+// distance to that face.  Velocities are corrected by four Jacobi passes (ConvertedSubScene.unity
+// :235, four solver iterations): every pass reads the velocities of the pass before, each dynamic
+// body sums the impulses of all its contacts -- as corner owner and as container -- computed with
+// its inverse mass and inertia scaled by its number of contacts (mass splitting, so that the summed
+// corrections do not overshoot).  Per contact: restitution max(e_X, e_Y) (CombineMode 2), a
+// penetration bias 0.2 * depth / dt, Coulomb friction sqrt(mu_X * mu_Y) (CombineMode 0: the
+// BuoyancyObject's 0.5 against another such object, 0 against the walls; :742-751).
+struct BodyRO {
+    float c[3], R[9], he[3], invMass, invI[3], e, mu;
+    bool dynamic;
+};
+__device__ __forceinline__ BodyRO body_view(const float *__restrict__ state, int k)
+{
+    const float *b = state + 25 * k;
+    BodyRO v;
+    for (int a = 0; a < 3; a++) { v.c[a] = b[a]; v.he[a] = b[7 + a]; v.invI[a] = b[17 + a]; }
+    quat_to_mat(b + 3, v.R);
+    v.invMass = b[16];
+    v.e = b[20];
+    v.mu = b[21];
+    v.dynamic = v.invMass != 0.f || v.invI[0] != 0.f || v.invI[1] != 0.f || v.invI[2] != 0.f;
+    return v;
+}
+// world-space inverse inertia applied to v:  R diag(invI) R^T v
+__device__ __forceinline__ void inv_inertia(const BodyRO &B, const float *v, float *o)
+{
+    float l[3];
+    l[0] = ((B.R[0] * v[0] + B.R[3] * v[1]) + B.R[6] * v[2]) * B.invI[0];
+    l[1] = ((B.R[1] * v[0] + B.R[4] * v[1]) + B.R[7] * v[2]) * B.invI[1];
+    l[2] = ((B.R[2] * v[0] + B.R[5] * v[1]) + B.R[8] * v[2]) * B.invI[2];
+    o[0] = (B.R[0] * l[0] + B.R[1] * l[1]) + B.R[2] * l[2];
+    o[1] = (B.R[3] * l[0] + B.R[4] * l[1]) + B.R[5] * l[2];
+    o[2] = (B.R[6] * l[0] + B.R[7] * l[1]) + B.R[8] * l[2];
+}
+__device__ __forceinline__ void cross3(const float *a, const float *b, float *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// corner ci of X inside Y?  n: world normal out of Y, rX / rY: the corner relative to the centres
+__device__ __forceinline__ bool corner_contact(const BodyRO &X, const BodyRO &Y, int ci, float *n,
+                                               float &depth, float *rX, float *rY)
+{
+    const float hl[3] = {(ci & 1) ? X.he[0] : -X.he[0], (ci & 2) ? X.he[1] : -X.he[1],
+                         (ci & 4) ? X.he[2] : -X.he[2]};
+    rX[0] = (X.R[0] * hl[0] + X.R[1] * hl[1]) + X.R[2] * hl[2];
+    rX[1] = (X.R[3] * hl[0] + X.R[4] * hl[1]) + X.R[5] * hl[2];
+    rX[2] = (X.R[6] * hl[0] + X.R[7] * hl[1]) + X.R[8] * hl[2];
+    for (int a = 0; a < 3; a++) rY[a] = (X.c[a] + rX[a]) - Y.c[a];
+    float q[3];
+    q[0] = (Y.R[0] * rY[0] + Y.R[3] * rY[1]) + Y.R[6] * rY[2];
+    q[1] = (Y.R[1] * rY[0] + Y.R[4] * rY[1]) + Y.R[7] * rY[2];
+    q[2] = (Y.R[2] * rY[0] + Y.R[5] * rY[1]) + Y.R[8] * rY[2];
+    for (int a = 0; a < 3; a++)
+        if (!(Y.he[a] - fabsf(q[a]) > 0.f)) return false; // outside (or on) the box
+    // the face the corner came in through: the one X's centre is farthest outside of, in units of
+    // Y's half extents (the nearest face would flip to a side face near an edge)
+    const float dc[3] = {X.c[0] - Y.c[0], X.c[1] - Y.c[1], X.c[2] - Y.c[2]};
+    float cq[3];
+    cq[0] = (Y.R[0] * dc[0] + Y.R[3] * dc[1]) + Y.R[6] * dc[2];
+    cq[1] = (Y.R[1] * dc[0] + Y.R[4] * dc[1]) + Y.R[7] * dc[2];
+    cq[2] = (Y.R[2] * dc[0] + Y.R[5] * dc[1]) + Y.R[8] * dc[2];
+    int best = 0;
+    float bests = fabsf(cq[0]) / Y.he[0];
+    for (int a = 1; a < 3; a++) {
+        const float sa = fabsf(cq[a]) / Y.he[a];
+        if (sa > bests) { best = a; bests = sa; }
+    }
+    const float sgn = cq[best] < 0.f ? -1.f : 1.f;
+    const float bestd = Y.he[best] - sgn * q[best];
+    n[0] = Y.R[best] * sgn;     // column `best` of R
+    n[1] = Y.R[3 + best] * sgn;
+    n[2] = Y.R[6 + best] * sgn;
+    depth = bestd;
+    return true;
+}
+// impulse J on X (and -J on Y) of one contact, from the velocities vel[6*k..] of the pass before
+__device__ __forceinline__ void contact_impulse(const BodyRO &X, const BodyRO &Y, const float *vX,
+                                                const float *vY, float nX, float nY, const float *n,
+                                                float depth, const float *rX, const float *rY,
+                                                float dt, float *J)
+{
+    float wX[3], wY[3], vrel[3];
+    cross3(vX + 3, rX, wX);
+    cross3(vY + 3, rY, wY);
+    for (int a = 0; a < 3; a++) vrel[a] = (vX[a] + wX[a]) - (vY[a] + wY[a]);
+    const float vn = (vrel[0] * n[0] + vrel[1] * n[1]) + vrel[2] * n[2];
+    const float e = fmaxf(X.e, Y.e), mu = sqrtf(X.mu * Y.mu);
+    const float wanted = fmaxf(vn < 0.f ? -e * vn : 0.f, 0.2f * depth / dt);
+    const float dvn = wanted - vn;
+    J[0] = J[1] = J[2] = 0.f;
+    if (!(dvn > 0.f)) return;
+    auto kdir = [&](const float *d) {
+        float cx[3], cy[3], ix[3], iy[3];
+        cross3(rX, d, cx);
+        cross3(rY, d, cy);
+        inv_inertia(X, cx, ix);
+        inv_inertia(Y, cy, iy);
+        return (nX * X.invMass + nY * Y.invMass) +
+               (nX * ((cx[0] * ix[0] + cx[1] * ix[1]) + cx[2] * ix[2]) +
+                nY * ((cy[0] * iy[0] + cy[1] * iy[1]) + cy[2] * iy[2]));
+    };
+    const float jn = dvn / kdir(n);
+    float t[3];
+    for (int a = 0; a < 3; a++) t[a] = vrel[a] - vn * n[a];
+    const float vt = sqrtf((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+    float jt = 0.f;
+    if (mu > 0.f && vt > 1.0e-6f) {
+        for (int a = 0; a < 3; a++) t[a] = t[a] / vt;
+        jt = fminf(mu * jn, vt / kdir(t));
+    }
+    for (int a = 0; a < 3; a++) J[a] = jn * n[a] - jt * t[a];
+}
+__device__ __forceinline__ bool aabb_overlap(const float4 *__restrict__ aabb, int a, int b)
+{
+    const float4 al = aabb[2 * a], ah = aabb[2 * a + 1], bl = aabb[2 * b], bh = aabb[2 * b + 1];
+    return !(ah.x < bl.x || al.x > bh.x || ah.y < bl.y || al.y > bh.y || ah.z < bl.z || al.z > bh.z);
+}
+
+// number of contacts of every body, and its velocities copied to vel (6 floats a body)
+__global__ void k_body_contact_count(const float *__restrict__ state, const float4 *__restrict__ aabb,
+                                     int nboxes, float *__restrict__ ncontacts, float *__restrict__ vel)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nboxes) return;
+    for (int a = 0; a < 6; a++) vel[6 * k + a] = state[25 * k + 10 + a];
+    const BodyRO A = body_view(state, k);
+    int cnt = 0;
+    for (int j = 0; j < nboxes; j++) {
+        if (j == k || !aabb_overlap(aabb, k, j)) continue;
+        const BodyRO B = body_view(state, j);
+        if (!A.dynamic && !B.dynamic) continue;
+        float n[3], d, r1[3], r2[3];
+        for (int ci = 0; ci < 8; ci++) {
+            if (corner_contact(A, B, ci, n, d, r1, r2)) cnt++;
+            if (corner_contact(B, A, ci, n, d, r1, r2)) cnt++;
+        }
+    }
+    ncontacts[k] = (float)max(cnt, 1);
+}
+
+// one Jacobi pass: vin -> vout
+__global__ void k_body_contact_pass(const float *__restrict__ state, const float4 *__restrict__ aabb,
+                                    const float *__restrict__ ncontacts, int nboxes, float dt,
+                                    const float *__restrict__ vin, float *__restrict__ vout)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nboxes) return;
+    float v[6];
+    for (int a = 0; a < 6; a++) v[a] = vin[6 * k + a];
+    const BodyRO A = body_view(state, k);
+    if (A.dynamic) {
+        float dl[3] = {0.f, 0.f, 0.f}, da[3] = {0.f, 0.f, 0.f};
+        const float nA = ncontacts[k];
+        for (int j = 0; j < nboxes; j++) {
+            if (j == k || !aabb_overlap(aabb, k, j)) continue;
+            const BodyRO B = body_view(state, j);
+            const float nB = ncontacts[j];
+            float n[3], d, rX[3], rY[3], J[3], tq[3], w[3];
+            for (int ci = 0; ci < 8; ci++) {
+                if (corner_contact(A, B, ci, n, d, rX, rY)) { // A's corner in B: +J on A
+                    contact_impulse(A, B, vin + 6 * k, vin + 6 * j, nA, nB, n, d, rX, rY, dt, J);
+                    cross3(rX, J, tq);
+                    inv_inertia(A, tq, w);
+                    for (int a = 0; a < 3; a++) { dl[a] = dl[a] + J[a] * A.invMass; da[a] = da[a] + w[a]; }
+                }
+                if (corner_contact(B, A, ci, n, d, rX, rY)) { // B's corner in A: -J on A
+                    contact_impulse(B, A, vin + 6 * j, vin + 6 * k, nB, nA, n, d, rX, rY, dt, J);
+                    cross3(rY, J, tq);
+                    inv_inertia(A, tq, w);
+                    for (int a = 0; a < 3; a++) { dl[a] = dl[a] - J[a] * A.invMass; da[a] = da[a] - w[a]; }
+                }
+            }
+        }
+        for (int a = 0; a < 3; a++) { v[a] = v[a] + dl[a]; v[3 + a] = v[3 + a] + da[a]; }
+    }
+    for (int a = 0; a < 6; a++) vout[6 * k + a] = v[a];
 }

@@ -154,6 +154,7 @@ struct SphCtx {
     DevBuf<float> boxState;
     DevBuf<DevBox> devBoxes;
     DevBuf<float4> boxAabb, chunkAabb; // world bounds per box / per SPH_BOX_CHUNK boxes
+    DevBuf<float> bodyVelA, bodyVelB, bodyNc; // box-box contact passes: velocities (6 a body), contact counts
     DevBuf<float> bodyImpulse;
 
     // sort scratch
@@ -760,7 +761,7 @@ int sph_destroy(SphCtx *c)
     release(c->dmats); release(c->table); release(c->btable); release(c->ttable); release(c->tileList); release(c->tileCtl); release(c->blockList); release(c->gcellList); release(c->pool);
     release(c->bpos3); release(c->bpar3); release(c->bposmIn); release(c->bposm);
     release(c->bkeysA); release(c->bkeysB); release(c->bvalsA); release(c->bvalsB);
-    release(c->boxState); release(c->devBoxes); release(c->bodyImpulse); release(c->boxAabb); release(c->chunkAabb);
+    release(c->boxState); release(c->devBoxes); release(c->bodyImpulse); release(c->boxAabb); release(c->chunkAabb); release(c->bodyVelA); release(c->bodyVelB); release(c->bodyNc);
     release(c->hist); release(c->rowTotal); release(c->partial);
     for (const EventPair &ep : c->pending) {
         (void)hipEventDestroy(ep.a);
@@ -882,8 +883,8 @@ int sph_set_colliders(SphCtx *c, const SphBox *boxes, int32_t K)
     HIPCHK(c, hipMemcpyAsync(c->boxState.p, boxes, sizeof(SphBox) * (size_t)K,
                              hipMemcpyHostToDevice, c->stream));
     k_bodies<<<blocks_for(K, 64), 64, 0, c->stream>>>(c->boxState.p, c->devBoxes.p, c->boxAabb.p,
-                                                      c->bodyImpulse.p, K, 0, 0.f, 0.f, 0.f, 0.f,
-                                                      0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+                                                      c->bodyImpulse.p, nullptr, K, 0, 0.f, 0.f, 0.f,
+                                                      0.f, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
     k_box_chunks<<<blocks_for(blocks_for(K, SPH_BOX_CHUNK), 64), 64, 0, c->stream>>>(
         c->boxAabb.p, K, c->chunkAabb.p);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1299,13 +1300,34 @@ static int launch_bodies(SphCtx *c, const SphParams *p)
 {
     if (c->nboxes <= 0) return SPH_OK;
     StageTimer t(c, SPH_T_BODIES);
-    k_bodies<<<blocks_for(c->nboxes, 64), 64, 0, c->stream>>>(
-        c->boxState.p, c->devBoxes.p, c->boxAabb.p, c->bodyImpulse.p, c->nboxes, 1, p->dt,
-        p->gravity[0], p->gravity[1], p->gravity[2], p->boundBodies, p->bodyMin[0], p->bodyMin[1],
-        p->bodyMin[2], p->bodyMax[0], p->bodyMax[1], p->bodyMax[2]);
+    const int K = c->nboxes, nb = blocks_for(K, 64);
+#define LAUNCH_BODIES(MODE, VELIN)                                                               \
+    k_bodies<<<nb, 64, 0, c->stream>>>(c->boxState.p, c->devBoxes.p, c->boxAabb.p,               \
+                                       c->bodyImpulse.p, VELIN, K, MODE, p->dt, p->gravity[0],   \
+                                       p->gravity[1], p->gravity[2], p->boundBodies,             \
+                                       p->bodyMin[0], p->bodyMin[1], p->bodyMin[2],              \
+                                       p->bodyMax[0], p->bodyMax[1], p->bodyMax[2])
+    if (p->bodyContacts && c->anyDynamicBox && K >= 2) {
+        // velocities -> contacts between boxes (count, four Jacobi passes) -> tank contacts, pose
+        int rc = ensure(c, c->bodyVelA, (size_t)6 * K);
+        if (!rc) rc = ensure(c, c->bodyVelB, (size_t)6 * K);
+        if (!rc) rc = ensure(c, c->bodyNc, (size_t)K);
+        if (rc) return rc;
+        LAUNCH_BODIES(2, nullptr);
+        k_body_contact_count<<<nb, 64, 0, c->stream>>>(c->boxState.p, c->boxAabb.p, K, c->bodyNc.p,
+                                                       c->bodyVelA.p);
+        for (int it = 0; it < 4; it++)
+            k_body_contact_pass<<<nb, 64, 0, c->stream>>>(
+                c->boxState.p, c->boxAabb.p, c->bodyNc.p, K, p->dt,
+                (it & 1) ? c->bodyVelB.p : c->bodyVelA.p, (it & 1) ? c->bodyVelA.p : c->bodyVelB.p);
+        LAUNCH_BODIES(3, c->bodyVelA.p);
+    } else {
+        LAUNCH_BODIES(1, nullptr);
+    }
+#undef LAUNCH_BODIES
     if (c->anyDynamicBox) // (static boxes keep the chunk bounds of sph_set_colliders)
-        k_box_chunks<<<blocks_for(blocks_for(c->nboxes, SPH_BOX_CHUNK), 64), 64, 0, c->stream>>>(
-            c->boxAabb.p, c->nboxes, c->chunkAabb.p);
+        k_box_chunks<<<blocks_for(blocks_for(K, SPH_BOX_CHUNK), 64), 64, 0, c->stream>>>(
+            c->boxAabb.p, K, c->chunkAabb.p);
     HIPCHK(c, hipGetLastError());
     return SPH_OK;
 }

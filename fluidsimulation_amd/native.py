@@ -48,7 +48,7 @@ class SphParams(C.Structure):
     _fields_ = [("dt", C.c_float), ("kernelRadiusRate", C.c_float), ("gravity", C.c_float * 3),
                 ("gridSize", C.c_float), ("particleRestitution", C.c_float),
                 ("boundBodies", C.c_int32), ("bodyMin", C.c_float * 3),
-                ("bodyMax", C.c_float * 3)]
+                ("bodyMax", C.c_float * 3), ("bodyContacts", C.c_int32)]
 
 
 class SphConfig(C.Structure):
@@ -142,13 +142,14 @@ def load():
 
 
 def make_params(grid_size, dt=1.0 / 60.0, rate=4.0, gravity=(0.0, -9.81, 0.0),
-                particle_restitution=0.5, body_bounds=None):
+                particle_restitution=0.5, body_bounds=None, body_contacts=False):
     p = SphParams()
     p.dt = dt
     p.kernelRadiusRate = rate
     p.gravity[:] = gravity
     p.gridSize = grid_size
     p.particleRestitution = particle_restitution
+    p.bodyContacts = 1 if body_contacts else 0
     if body_bounds is not None:
         p.boundBodies = 1
         p.bodyMin[:] = [float(v) for v in body_bounds[0]]

@@ -154,6 +154,7 @@ public unsafe partial class FluidSPHByHIPSystem : SystemBase
             gridSize = gridSize[0],
             particleRestitution = 0.5f, // Particle.prefab:142-146
             boundBodies = 0,
+            bodyContacts = 1, // full mode: the walls are boxes, the BuoyancyObject rests on them
         };
         par.gravity[0] = 0f; par.gravity[1] = -9.81f; par.gravity[2] = 0f; // FluidSPHByCPUSystem.cs:140
 

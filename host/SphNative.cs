@@ -57,6 +57,7 @@ public static unsafe class SphNative
         public int boundBodies;
         public fixed float bodyMin[3];
         public fixed float bodyMax[3];
+        public int bodyContacts;
     }
 
     [StructLayout(LayoutKind.Sequential)]

@@ -66,6 +66,8 @@ typedef struct SphParams {
     int32_t boundBodies;       /* !=0: keep dynamic boxes' AABBs inside [bodyMin,bodyMax]  */
     float bodyMin[3];
     float bodyMax[3];
+    int32_t bodyContacts;      /* !=0: contacts between boxes (a corner of one inside another:
+                                  dynamic-dynamic and dynamic-static), DESIGN.md section 6       */
 } SphParams;
 
 /* Oriented box collider / rigid body (row I; Unity Physics / Havok in the reference, configured

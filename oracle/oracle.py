@@ -197,7 +197,7 @@ def integrate_particles(pos, vel, inv_mass, params, boxes, dt, particle_restitut
     return pos, vel, imp[:len(boxes)]
 
 
-def integrate_bodies(boxes, impulses, dt, gravity=(0.0, -9.81, 0.0), bounds=None):
+def integrate_bodies(boxes, impulses, dt, gravity=(0.0, -9.81, 0.0), bounds=None, contacts=False):
     boxes = _f32(boxes).reshape(-1, BOX_FLOATS).copy()
     imp = _f32(impulses).reshape(-1, 6)
     g = _f32(gravity)
@@ -207,8 +207,8 @@ def integrate_bodies(boxes, impulses, dt, gravity=(0.0, -9.81, 0.0), bounds=None
     else:
         bmin, bmax = _f32(bounds[0]), _f32(bounds[1])
         bounded = 1
-    lib().orc_integrate_bodies(_p(boxes), C.c_int(len(boxes)), _p(imp), C.c_float(dt), _p(g),
-                               C.c_int(bounded), _p(bmin), _p(bmax))
+    lib().orc_integrate_bodies2(_p(boxes), C.c_int(len(boxes)), _p(imp), C.c_float(dt), _p(g),
+                                C.c_int(bounded), _p(bmin), _p(bmax), C.c_int(1 if contacts else 0))
     return boxes
 
 

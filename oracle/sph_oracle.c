@@ -612,30 +612,35 @@ ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMas
     free(mats);
 }
 
-/* rigid bodies: apply the particles' reaction, gravity, damping; when bounded != 0 solve the
- * corner contacts with the planes of [bmin,bmax]; integrate pose; a last positional clamp keeps
- * the body's world AABB inside (whatever four iterations left over). */
-ORC_API void orc_integrate_bodies(OrcBox *boxes, int nboxes, const float *body_impulse, float dt,
-                                  const float *gravity, int bounded, const float *bmin,
-                                  const float *bmax)
+/* rigid bodies (row I, build-defined): (1) the particles' reaction, gravity, damping; (2) when
+ * contacts != 0, contacts between boxes (below); (3) when bounded != 0 the corner contacts with the
+ * planes of [bmin,bmax]; pose integration; a last positional clamp of the world AABB. */
+static int box_dynamic(const OrcBox *bx)
 {
-    for (int k = 0; k < nboxes; k++) {
-        OrcBox *bx = &boxes[k];
-        int dynamic = bx->invMass != 0.0f || bx->invInertia[0] != 0.0f ||
-                      bx->invInertia[1] != 0.0f || bx->invInertia[2] != 0.0f;
-        if (!dynamic) continue;
+    return bx->invMass != 0.0f || bx->invInertia[0] != 0.0f || bx->invInertia[1] != 0.0f ||
+           bx->invInertia[2] != 0.0f;
+}
+
+static void body_velocities(OrcBox *bx, const float *imp6, float dt, const float *gravity)
+{
         float m[9], loc[3], dw[3];
         quat_to_mat(bx->rot, m);
-        mat_tmul(m, body_impulse + 6 * k + 3, loc);
+        mat_tmul(m, imp6 + 3, loc);
         for (int a = 0; a < 3; a++) loc[a] = loc[a] * bx->invInertia[a];
         mat_mul(m, loc, dw);
         float ld = fminf(fmaxf(1.0f - bx->linDamping * dt, 0.0f), 1.0f);
         float ad = fminf(fmaxf(1.0f - bx->angDamping * dt, 0.0f), 1.0f);
         for (int a = 0; a < 3; a++) {
-            bx->linVel[a] = (bx->linVel[a] + body_impulse[6 * k + a] * bx->invMass +
+            bx->linVel[a] = (bx->linVel[a] + imp6[a] * bx->invMass +
                              gravity[a] * bx->gravityFactor * dt) * ld;
             bx->angVel[a] = (bx->angVel[a] + dw[a]) * ad;
         }
+}
+
+static void body_rest(OrcBox *bx, float dt, int bounded, const float *bmin, const float *bmax)
+{
+        float m[9];
+        quat_to_mat(bx->rot, m);
         /* contacts of the box's eight corners with the six planes of [bmin,bmax] (the tank's
          * walls), four passes of sequential impulses as the scene's four solver iterations
          * (ConvertedSubScene.unity:235): speculative, inelastic (restitution max(0,0),
@@ -704,7 +709,198 @@ ORC_API void orc_integrate_bodies(OrcBox *boxes, int nboxes, const float *body_i
                 }
             }
         }
+}
+
+/* ---- contacts between boxes: a corner of X inside Y; normal = Y's nearest face.  Four Jacobi
+ * passes with mass splitting; restitution max, bias 0.2*depth/dt, friction sqrt(muX*muY). */
+static void w_inv_inertia(const OrcBox *B, const float *R, const float *v, float *o)
+{
+    float l[3];
+    mat_tmul(R, v, l);
+    for (int a = 0; a < 3; a++) l[a] = l[a] * B->invInertia[a];
+    mat_mul(R, l, o);
+}
+static void cross3f(const float *a, const float *b, float *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static int corner_contact(const OrcBox *X, const float *RX, const OrcBox *Y, const float *RY, int ci,
+                          float *n, float *depth, float *rX, float *rY)
+{
+    float hl[3] = {(ci & 1) ? X->halfExtents[0] : -X->halfExtents[0],
+                   (ci & 2) ? X->halfExtents[1] : -X->halfExtents[1],
+                   (ci & 4) ? X->halfExtents[2] : -X->halfExtents[2]};
+    mat_mul(RX, hl, rX);
+    for (int a = 0; a < 3; a++) rY[a] = (X->center[a] + rX[a]) - Y->center[a];
+    float q[3];
+    mat_tmul(RY, rY, q);
+    for (int a = 0; a < 3; a++)
+        if (!(Y->halfExtents[a] - fabsf(q[a]) > 0.0f)) return 0; /* outside (or on) the box */
+    /* the face the corner came in through: the one X's centre is farthest outside of, in units
+     * of Y's half extents (the nearest face would flip to a side face near an edge) */
+    float dc[3] = {X->center[0] - Y->center[0], X->center[1] - Y->center[1], X->center[2] - Y->center[2]};
+    float cq[3];
+    mat_tmul(RY, dc, cq);
+    int best = 0;
+    float bests = fabsf(cq[0]) / Y->halfExtents[0];
+    for (int a = 1; a < 3; a++) {
+        float sa = fabsf(cq[a]) / Y->halfExtents[a];
+        if (sa > bests) { best = a; bests = sa; }
     }
+    float sgn = cq[best] < 0.0f ? -1.0f : 1.0f;
+    float bestd = Y->halfExtents[best] - sgn * q[best];
+    n[0] = RY[best] * sgn;
+    n[1] = RY[3 + best] * sgn;
+    n[2] = RY[6 + best] * sgn;
+    *depth = bestd;
+    return 1;
+}
+static float k_dir(const OrcBox *X, const float *RX, const OrcBox *Y, const float *RY, float nX,
+                   float nY, const float *rX, const float *rY, const float *d)
+{
+    float cx[3], cy[3], ix[3], iy[3];
+    cross3f(rX, d, cx);
+    cross3f(rY, d, cy);
+    w_inv_inertia(X, RX, cx, ix);
+    w_inv_inertia(Y, RY, cy, iy);
+    return (nX * X->invMass + nY * Y->invMass) +
+           (nX * ((cx[0] * ix[0] + cx[1] * ix[1]) + cx[2] * ix[2]) +
+            nY * ((cy[0] * iy[0] + cy[1] * iy[1]) + cy[2] * iy[2]));
+}
+static void contact_impulse(const OrcBox *X, const float *RX, const OrcBox *Y, const float *RY,
+                            const float *vX, const float *vY, float nX, float nY, const float *n,
+                            float depth, const float *rX, const float *rY, float dt, float *J)
+{
+    float wX[3], wY[3], vrel[3];
+    cross3f(vX + 3, rX, wX);
+    cross3f(vY + 3, rY, wY);
+    for (int a = 0; a < 3; a++) vrel[a] = (vX[a] + wX[a]) - (vY[a] + wY[a]);
+    float vn = (vrel[0] * n[0] + vrel[1] * n[1]) + vrel[2] * n[2];
+    float e = fmaxf(X->restitution, Y->restitution), mu = sqrtf(X->friction * Y->friction);
+    float wanted = fmaxf(vn < 0.0f ? -e * vn : 0.0f, 0.2f * depth / dt);
+    float dvn = wanted - vn;
+    J[0] = J[1] = J[2] = 0.0f;
+    if (!(dvn > 0.0f)) return;
+    float jn = dvn / k_dir(X, RX, Y, RY, nX, nY, rX, rY, n);
+    float t[3];
+    for (int a = 0; a < 3; a++) t[a] = vrel[a] - vn * n[a];
+    float vt = sqrtf((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+    float jt = 0.0f;
+    if (mu > 0.0f && vt > 1.0e-6f) {
+        for (int a = 0; a < 3; a++) t[a] = t[a] / vt;
+        jt = fminf(mu * jn, vt / k_dir(X, RX, Y, RY, nX, nY, rX, rY, t));
+    }
+    for (int a = 0; a < 3; a++) J[a] = jn * n[a] - jt * t[a];
+}
+static void box_aabb(const OrcBox *bx, const float *R, float *lo, float *hi)
+{
+    for (int a = 0; a < 3; a++) {
+        float ext = (fabsf(R[3 * a]) * bx->halfExtents[0] + fabsf(R[3 * a + 1]) * bx->halfExtents[1]) +
+                    fabsf(R[3 * a + 2]) * bx->halfExtents[2];
+        lo[a] = bx->center[a] - ext;
+        hi[a] = bx->center[a] + ext;
+    }
+}
+static void body_contacts(OrcBox *boxes, int nboxes, float dt)
+{
+    float *R = (float *)malloc(sizeof(float) * 9 * (size_t)nboxes);
+    float *lo = (float *)malloc(sizeof(float) * 3 * (size_t)nboxes);
+    float *hi = (float *)malloc(sizeof(float) * 3 * (size_t)nboxes);
+    float *nc = (float *)malloc(sizeof(float) * (size_t)nboxes);
+    float *va = (float *)malloc(sizeof(float) * 6 * (size_t)nboxes);
+    float *vb = (float *)malloc(sizeof(float) * 6 * (size_t)nboxes);
+    for (int k = 0; k < nboxes; k++) {
+        quat_to_mat(boxes[k].rot, R + 9 * k);
+        box_aabb(&boxes[k], R + 9 * k, lo + 3 * k, hi + 3 * k);
+        for (int a = 0; a < 3; a++) {
+            va[6 * k + a] = boxes[k].linVel[a];
+            va[6 * k + 3 + a] = boxes[k].angVel[a];
+        }
+    }
+#define OVERLAP(a, b)                                                                            \
+    (!(hi[3 * (a)] < lo[3 * (b)] || lo[3 * (a)] > hi[3 * (b)] || hi[3 * (a) + 1] < lo[3 * (b) + 1] ||  \
+       lo[3 * (a) + 1] > hi[3 * (b) + 1] || hi[3 * (a) + 2] < lo[3 * (b) + 2] ||                  \
+       lo[3 * (a) + 2] > hi[3 * (b) + 2]))
+    for (int k = 0; k < nboxes; k++) {
+        int cnt = 0;
+        for (int j = 0; j < nboxes; j++) {
+            if (j == k || !OVERLAP(k, j)) continue;
+            if (!box_dynamic(&boxes[k]) && !box_dynamic(&boxes[j])) continue;
+            float n[3], d, r1[3], r2[3];
+            for (int ci = 0; ci < 8; ci++) {
+                cnt += corner_contact(&boxes[k], R + 9 * k, &boxes[j], R + 9 * j, ci, n, &d, r1, r2);
+                cnt += corner_contact(&boxes[j], R + 9 * j, &boxes[k], R + 9 * k, ci, n, &d, r1, r2);
+            }
+        }
+        nc[k] = (float)(cnt > 1 ? cnt : 1);
+    }
+    for (int it = 0; it < 4; it++) {
+        const float *vin = (it & 1) ? vb : va;
+        float *vout = (it & 1) ? va : vb;
+        for (int k = 0; k < nboxes; k++) {
+            const OrcBox *A = &boxes[k];
+            const float *RA = R + 9 * k;
+            float v[6];
+            for (int a = 0; a < 6; a++) v[a] = vin[6 * k + a];
+            if (box_dynamic(A)) {
+                float dl[3] = {0.0f, 0.0f, 0.0f}, da[3] = {0.0f, 0.0f, 0.0f};
+                for (int j = 0; j < nboxes; j++) {
+                    if (j == k || !OVERLAP(k, j)) continue;
+                    const OrcBox *B = &boxes[j];
+                    const float *RB = R + 9 * j;
+                    float n[3], d, rX[3], rY[3], J[3], tq[3], w[3];
+                    for (int ci = 0; ci < 8; ci++) {
+                        if (corner_contact(A, RA, B, RB, ci, n, &d, rX, rY)) {
+                            contact_impulse(A, RA, B, RB, vin + 6 * k, vin + 6 * j, nc[k], nc[j], n, d, rX, rY, dt, J);
+                            cross3f(rX, J, tq);
+                            w_inv_inertia(A, RA, tq, w);
+                            for (int a = 0; a < 3; a++) { dl[a] = dl[a] + J[a] * A->invMass; da[a] = da[a] + w[a]; }
+                        }
+                        if (corner_contact(B, RB, A, RA, ci, n, &d, rX, rY)) {
+                            contact_impulse(B, RB, A, RA, vin + 6 * j, vin + 6 * k, nc[j], nc[k], n, d, rX, rY, dt, J);
+                            cross3f(rY, J, tq);
+                            w_inv_inertia(A, RA, tq, w);
+                            for (int a = 0; a < 3; a++) { dl[a] = dl[a] - J[a] * A->invMass; da[a] = da[a] - w[a]; }
+                        }
+                    }
+                }
+                for (int a = 0; a < 3; a++) { v[a] = v[a] + dl[a]; v[3 + a] = v[3 + a] + da[a]; }
+            }
+            for (int a = 0; a < 6; a++) vout[6 * k + a] = v[a];
+        }
+    }
+#undef OVERLAP
+    for (int k = 0; k < nboxes; k++)
+        if (box_dynamic(&boxes[k]))
+            for (int a = 0; a < 3; a++) {
+                boxes[k].linVel[a] = va[6 * k + a];
+                boxes[k].angVel[a] = va[6 * k + 3 + a];
+            }
+    free(R); free(lo); free(hi); free(nc); free(va); free(vb);
+}
+
+ORC_API void orc_integrate_bodies2(OrcBox *boxes, int nboxes, const float *body_impulse, float dt,
+                                   const float *gravity, int bounded, const float *bmin,
+                                   const float *bmax, int contacts)
+{
+    int any = 0;
+    for (int k = 0; k < nboxes; k++)
+        if (box_dynamic(&boxes[k])) {
+            body_velocities(&boxes[k], body_impulse + 6 * k, dt, gravity);
+            any = 1;
+        }
+    if (contacts && any && nboxes >= 2) body_contacts(boxes, nboxes, dt);
+    for (int k = 0; k < nboxes; k++)
+        if (box_dynamic(&boxes[k])) body_rest(&boxes[k], dt, bounded, bmin, bmax);
+}
+
+ORC_API void orc_integrate_bodies(OrcBox *boxes, int nboxes, const float *body_impulse, float dt,
+                                  const float *gravity, int bounded, const float *bmin,
+                                  const float *bmax)
+{
+    orc_integrate_bodies2(boxes, nboxes, body_impulse, dt, gravity, bounded, bmin, bmax, 0);
 }
 
 /* density field for rendering (no counterpart in the reference's code; its roadmap item

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_reference_components():
     # FluidParticleComponent 4 x f32, BoundaryParticleComponent 3 x f32 (checked by
     # static_asserts in the library too); SphParams / SphGrid / SphTimings mirror the header
-    assert C.sizeof(native.SphParams) == 4 * 14
+    assert C.sizeof(native.SphParams) == 4 * 15
     assert C.sizeof(native.SphGrid) == 4 * 8
     assert C.sizeof(native.SphConfig) == 16
     assert C.sizeof(native.SphTimings) == 9 * 8 + 9 * 8 + 8
