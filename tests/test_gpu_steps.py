@@ -223,12 +223,13 @@ def test_error_paths(ctx):
         ctx.hash_position(bad)
 
 
-@pytest.mark.parametrize("config", ["C2", "C3"])
+@pytest.mark.parametrize("config", ["C2", "C3", "C4"])
 def test_full_size_properties(ctx, oracle, config):
-    """C2 (1 M) and C3 (16.7 M particles, the size the metric is quoted on): size-independent
-    properties -- the permutation is a permutation, sorted by key with ties by id; the table
-    partitions [0, N); densities and forces of a sampled slab equal the oracle's computed on
-    that slab's neighbourhood."""
+    """C2 (1 M), C3 (16.7 M particles, the size the metric is quoted on) and the whole of C4 on one
+    GPU (134 M particles: record byte offsets pass 2^31, the largest size BASELINE.json names):
+    size-independent properties -- the permutation is a permutation, sorted by key with ties by
+    id; the table partitions [0, N); densities and forces of a sampled slab equal the oracle's
+    computed on that slab's neighbourhood."""
     sc = scene.make_config(config)
     p = load_scene(ctx, sc, debug=native.SPH_DEBUG_HASHES)
     ctx.hash_position(p)
