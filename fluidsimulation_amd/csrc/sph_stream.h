@@ -572,8 +572,8 @@ __global__ __launch_bounds__(256) void k_sample_density(
 }
 
 // ---- contacts between boxes (row I, build-defined; Unity Physics / Havok in the reference) ------
-// A contact is a corner of box X inside box Y: normal = Y's nearest face (out of Y), depth = the
-// distance to that face.  Velocities are corrected by four Jacobi passes (ConvertedSubScene.unity
+// A contact is a corner of box X inside box Y: normal = the face of Y that X's centre lies beyond
+// (in units of Y's half extents; out of Y), depth = the corner's distance below that face.  Velocities are corrected by four Jacobi passes (ConvertedSubScene.unity
 // :235, four solver iterations): every pass reads the velocities of the pass before, each dynamic
 // body sums the impulses of all its contacts -- as corner owner and as container -- computed with
 // its inverse mass and inertia scaled by its number of contacts (mass splitting, so that the summed

@@ -711,7 +711,8 @@ static void body_rest(OrcBox *bx, float dt, int bounded, const float *bmin, cons
         }
 }
 
-/* ---- contacts between boxes: a corner of X inside Y; normal = Y's nearest face.  Four Jacobi
+/* ---- contacts between boxes: a corner of X inside Y; normal = the face of Y that X's centre
+ * lies beyond (in units of Y's half extents).  This is build-defined (row I).  Four Jacobi
  * passes with mass splitting; restitution max, bias 0.2*depth/dt, friction sqrt(muX*muY). */
 static void w_inv_inertia(const OrcBox *B, const float *R, const float *v, float *o)
 {
