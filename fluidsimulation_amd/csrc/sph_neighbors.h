@@ -75,7 +75,7 @@
 #define NB_SLOTCAP 1408  // slot-table entries per block
 #define NB_MTAB 64       // materials whose loop constants are cached in LDS
 #define NB_POOL_PIECE 8192 // 16-byte units of plan pool a plan workgroup takes at a time (128 KB)
-#define NB_LIST_PIECE 16   // block-list entries it takes at a time
+#define NB_LIST_PIECE 16   // most block-list entries a plan workgroup can leave unused
 #ifndef NB_PLAN_WAVES
 #define NB_PLAN_WAVES 4 // waves per SIMD the plan kernel's register allocation must allow
 #endif
@@ -187,6 +187,15 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroup barrier for LDS hand-overs that does not wait for the wave's global memory operations:
+// __syncthreads() is  s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier, and vmcnt counts stores and returning
+// atomics too, so every barrier exposes the latency of whatever the wave has written since the last
+// one (the hit masks, the work-queue request).  Where only LDS contents change hands, this is enough.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // inclusive scan inside each row of 16 lanes (DPP row_shr, zeros shifted in)
@@ -557,12 +566,19 @@ __device__ void process_cell_global(const HaloTab &sh, const NbArgs &A, int lx, 
 // ------------------------------------------------------------------------------------------
 // PLAN KERNEL
 
+// The workgroup's next run of the block list, requested ahead of need (lane 0's registers: written
+// to LDS, the answer of the atomic would be waited for at once).
+struct ListAhead {
+    uint32_t at = 0, n = 0; // n = 0: nothing requested
+    int tilesLeft = 0;      // tiles this workgroup still has to plan after the current one
+};
+
 // The plan of one block (bx0.., sx x sy x sz cells, tile-local), by one wave.  Returns false,
 // having done nothing, when the block's halo, targets, units or slots do not fit.  hinfo.z = fluid
 // count | boundary count << 16.
 template <int sx, int sy, int sz>
 __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int tile, int bx0, int by0,
-                                           int bz0)
+                                           int bz0, ListAhead &la)
 {
     constexpr int hxN = sx + 2, hyN = sy + 2, nh = hxN * hyN * (sz + 2), ncells = sx * sy * sz;
     static_assert(nh <= 3 * 64 && ncells <= 64, "three halo cells and one block cell per lane");
@@ -655,15 +671,30 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
             sh.poolAt = atomicAdd(&A.ctl[NB_CTL_POOL], piece);
             sh.poolEnd = sh.poolAt + piece;
         }
+        // The neighbour kernels walk every entry of the list, and an unused one costs them a
+        // request with nothing to do: the first run has one entry per tile of this workgroup (most
+        // tiles are one block); when tiles fall into several blocks and the entries left no longer
+        // cover one per remaining tile, the next run is requested -- while there are still entries,
+        // so that its answer is not waited for.
         if (sh.listAt == sh.listEnd) {
-            sh.listAt = atomicAdd(&A.ctl[NB_CTL_BLOCKS], (uint32_t)NB_LIST_PIECE);
-            sh.listEnd = sh.listAt + NB_LIST_PIECE;
+            if (la.n == 0) {
+                la.n = (uint32_t)la.tilesLeft + 2;
+                la.at = atomicAdd(&A.ctl[NB_CTL_BLOCKS], la.n);
+            }
+            sh.listAt = la.at;
+            sh.listEnd = la.at + la.n;
+            la.n = 0;
         }
         const uint32_t o = sh.poolAt, i = sh.listAt;
         const bool ok = o + units16 <= A.poolCap && i < (uint32_t)A.blockCap;
         if (!ok) atomicOr(&A.ctl[NB_CTL_ERROR], 1u);
         sh.poolAt += units16;
         sh.listAt += 1;
+        const int left = (int)(sh.listEnd - sh.listAt);
+        if (la.n == 0 && left < la.tilesLeft) {
+            la.n = (uint32_t)min(la.tilesLeft - left + 1 + (la.tilesLeft >> 2), NB_LIST_PIECE);
+            la.at = atomicAdd(&A.ctl[NB_CTL_BLOCKS], la.n);
+        }
         off = ok ? (int)o : -1;
         idx = (int)i;
     }
@@ -733,8 +764,17 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
 __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_PLAN_WAVES, NB_PLAN_WAVES))) void k_plan(NbArgs A)
 {
     __shared__ PlanShared sh;
-    if (threadIdx.x == 0) sh.poolAt = sh.poolEnd = sh.listAt = sh.listEnd = 0;
     const uint32_t ntiles = A.ctl[NB_CTL_TILES];
+    const int myTiles = blockIdx.x < ntiles ? (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
+    ListAhead la;
+    if (threadIdx.x == 0) {
+        sh.poolAt = sh.poolEnd = sh.listAt = sh.listEnd = 0;
+        if (myTiles > 0) { // first run: one entry per tile
+            la.n = (uint32_t)myTiles;
+            la.at = atomicAdd(&A.ctl[NB_CTL_BLOCKS], la.n);
+        }
+    }
+    la.tilesLeft = myTiles;
     HaloRegs hr;
     int tile = 0, tileNext = 0;
     if (blockIdx.x < ntiles) {
@@ -746,6 +786,7 @@ __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_
         tile_lookup_store(sh.h, hr);
         wave_lds_fence();
         const int tileCur = tile;
+        la.tilesLeft--;
         if (ti + gridDim.x < ntiles) { // the next tile's look-ups, and the index of the one after
             tile = tileNext;
             tile_lookup_load(hr, tile, A);
@@ -755,16 +796,16 @@ __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_
         // cells for 32), else per y-half a 4x2x2 block (96 for 16), else per layer 4x2x1 (72 for
         // 8), 2x2x1 (48 for 4), single cells (27 for 1), else the global-memory path.  Blocks stay
         // long in x, the direction of the row windows.  One instantiation per shape.
-        if (plan_block<SPH_TX, SPH_TY, SPH_TZ>(sh, A, tileCur, 0, 0, 0)) continue;
+        if (plan_block<SPH_TX, SPH_TY, SPH_TZ>(sh, A, tileCur, 0, 0, 0, la)) continue;
         for (int yh = 0; yh < 2; yh++) {
-            if (plan_block<4, 2, 2>(sh, A, tileCur, 0, 2 * yh, 0)) continue;
+            if (plan_block<4, 2, 2>(sh, A, tileCur, 0, 2 * yh, 0, la)) continue;
             for (int z = 0; z < 2; z++) {
-                if (plan_block<4, 2, 1>(sh, A, tileCur, 0, 2 * yh, z)) continue;
+                if (plan_block<4, 2, 1>(sh, A, tileCur, 0, 2 * yh, z, la)) continue;
                 for (int xh = 0; xh < 2; xh++) {
-                    if (plan_block<2, 2, 1>(sh, A, tileCur, 2 * xh, 2 * yh, z)) continue;
+                    if (plan_block<2, 2, 1>(sh, A, tileCur, 2 * xh, 2 * yh, z, la)) continue;
                     for (int q = 0; q < 4; q++) {
                         const int bx = 2 * xh + (q & 1), by = 2 * yh + (q >> 1);
-                        if (plan_block<1, 1, 1>(sh, A, tileCur, bx, by, z)) continue;
+                        if (plan_block<1, 1, 1>(sh, A, tileCur, bx, by, z, la)) continue;
                         if (threadIdx.x == 0 && sh.h.fc[tile_halo_index(bx + 1, by + 1, z + 1)] > 0) {
                             const uint32_t idx = atomicAdd(&A.ctl[NB_CTL_GCELLS], 1u);
                             if (idx < (uint32_t)A.gcellCap) A.gcellList[idx] = make_int2(tileCur, bx | (by << 8) | (z << 16));
@@ -777,9 +818,12 @@ __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_
         wave_lds_fence(); // sh.h is rewritten by the next tile
     }
     // the unused entries of this workgroup's last run of the block list: empty blocks
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         for (uint32_t i = sh.listAt; i < sh.listEnd; i++)
             if (i < (uint32_t)A.blockCap) A.blockList[i] = make_int4(0, 0, 0, 0);
+        for (uint32_t i = la.at; i < la.at + la.n; i++) // a run requested ahead and not needed
+            if (i < (uint32_t)A.blockCap) A.blockList[i] = make_int4(0, 0, 0, 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -797,7 +841,8 @@ static_assert(sizeof(HaloTab) <= NB_PLANMAX, "the global-memory path keeps the t
 
 // one planned block
 template <bool FORCE, bool COUNT>
-__device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbArgs &A, const BlockHdr hdr)
+__device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbArgs &A, const BlockHdr hdr,
+                                           bool request, uint32_t chunk, uint32_t &pending)
 {
     constexpr int NT = FORCE ? NB_FTHREADS : NB_DTHREADS, NB_WAVES = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -838,7 +883,7 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
                     k2 < fc ? (uint32_t)(hi.y + k2) : 0x80000000u | (uint32_t)(hi.w + (k2 - fc));
         }
     }
-    __syncthreads();
+    lds_barrier();
     for (int p0 = w * 64; p0 < total; p0 += NT) { // wave-uniform
         if (p0 + lane < total) {
             const uint32_t src = ((const uint32_t *)recP)[4 * (p0 + lane)];
@@ -867,6 +912,9 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
     NB_STAMP((FORCE ? 16 : 8) + 1);
     __syncthreads();
     NB_STAMP((FORCE ? 16 : 8) + 2);
+    // the request for the workgroup's next chunk goes out here, behind the last barrier that waits
+    // for global memory (the image's DMA): its answer is needed when the chunk is done
+    if (request && threadIdx.x == 0) pending = atomicAdd(&A.ctl[A.queue], chunk) + gridDim.x * chunk;
 
     // 3. the units, dealt to the waves
     const char *baseP = (const char *)recP, *baseV = (const char *)recV;
@@ -1016,15 +1064,16 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
         ps.finish(A, S2, slice, writer, ti, fc4);
     }
     NB_STAMP((FORCE ? 16 : 8) + 3);
-    __syncthreads(); // the LDS image and the plan are reused by the next block
+    lds_barrier(); // the LDS image and the plan are reused by the next block
     NB_STAMP((FORCE ? 16 : 8) + 4);
 }
 
-// Persistent workgroups.  Blocks are taken from the list in chunks of NB_CHUNK through one
-// device-wide counter: a single word serves about 88 returning atomics per microsecond on this
-// chip, so one atomic per block would cost most of a millisecond per launch by itself; the next
-// chunk is requested while the current one is being processed.  Then the cells of the
-// global-memory path, one at a time.
+// Persistent workgroups.  Blocks are taken from the list in chunks of NB_CHUNK: workgroup b starts
+// with chunk b, the chunks behind the first gridDim.x come from one device-wide counter (a single
+// word serves about 88 returning atomics per microsecond on this chip, so one atomic per block
+// would cost most of a millisecond per launch by itself); the next chunk is requested while the
+// current one is being processed.  Then the cells of the global-memory path, one at a time, dealt
+// the same way.
 template <bool FORCE, bool COUNT>
 // second launch bound = waves per SIMD the register allocation must allow (what the LDS allows)
 __global__ __launch_bounds__(FORCE ? NB_FTHREADS : NB_DTHREADS)
@@ -1041,36 +1090,36 @@ void k_neighbors(NbArgs A)
     // blocks per request: NB_CHUNK when there is plenty of work, fewer when the whole list is only
     // a few blocks per workgroup (small scenes: the work must spread over all the workgroups)
     const uint32_t chunk = min((uint32_t)NB_CHUNK, max(1u, nblocks / (4u * gridDim.x)));
-    uint32_t pending = 0;
-    if (tid == 0) pending = atomicAdd(&A.ctl[A.queue], chunk);
+    uint32_t pending = blockIdx.x * chunk;
     for (;;) {
-        if (tid == 0) {
-            sh.next = pending;
-            if (pending < nblocks) pending = atomicAdd(&A.ctl[A.queue], chunk);
-        }
-        __syncthreads();
+        if (tid == 0) sh.next = pending;
+        lds_barrier();
         const uint32_t first = sh.next;
         if (first >= nblocks) break;
         const uint32_t n = min(chunk, nblocks - first);
         if (tid < (int)n) sh.hdr[tid] = A.blockList[first + tid];
-        __syncthreads();
-        // every thread has read `next` before thread 0 can write it again: each block has barriers
+        lds_barrier();
+        // every thread has read `next` before thread 0 can write it again: each block has barriers.
+        // The next chunk is requested inside the first block that is not an unused list entry.
+        bool requested = false;
         for (uint32_t i = 0; i < n; i++) {
             const BlockHdr hdr = sh.hdr[i];
-            if (hdr.w != 0) exec_block<FORCE, COUNT>(sh, A, hdr); // (0: unused list entry)
+            if (hdr.w == 0) continue; // unused list entry
+            exec_block<FORCE, COUNT>(sh, A, hdr, !requested, chunk, pending);
+            requested = true;
         }
+        if (!requested && tid == 0) pending = atomicAdd(&A.ctl[A.queue], chunk) + gridDim.x * chunk;
     }
     // cells whose 27-cell neighbourhood overflows the LDS image
     const uint32_t ncells = min(A.ctl[NB_CTL_GCELLS], (uint32_t)A.gcellCap);
     HaloTab &ht = *(HaloTab *)sh.plan;
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) sh.next = atomicAdd(&A.ctl[A.queue + 1], 1u);
-        __syncthreads();
-        const uint32_t i = sh.next;
-        if (i >= ncells) break;
+    for (uint32_t i = blockIdx.x; i < ncells;) {
         const int2 gc = A.gcellList[i];
         tile_lookup(ht, gc.x, A);
         process_cell_global<FORCE, COUNT>(ht, A, gc.y & 0xff, (gc.y >> 8) & 0xff, (gc.y >> 16) & 0xff);
+        __syncthreads();
+        if (tid == 0) sh.next = atomicAdd(&A.ctl[A.queue + 1], 1u) + gridDim.x;
+        __syncthreads();
+        i = sh.next;
     }
 }

@@ -1192,7 +1192,9 @@ static int ensure_plan(SphCtx *c, const SphParams *p, hipStream_t stream = nullp
     const size_t N = (size_t)c->n, tiles = (size_t)c->grid.tiles;
     const size_t tilesBound = std::min(tiles, N);
     const size_t planWgsMax = NB_PLAN_WGS_PER_CU * (size_t)std::max(1, c->prop.multiProcessorCount);
-    int rc = ensure(c, c->blockList, std::min(tilesBound * 32, N) + 64 + planWgsMax * NB_LIST_PIECE);
+    // (+ two entries per tile: a plan workgroup's runs of the list have one entry per tile it has
+    // still to plan, and a tile without fluid targets leaves its entry unused)
+    int rc = ensure(c, c->blockList, std::min(tilesBound * 32, N) + 2 * tilesBound + 64 + planWgsMax * (NB_LIST_PIECE + 2));
     if (!rc) rc = ensure(c, c->gcellList, (c->fallbackCap >= 0 ? N : (N + (size_t)c->nb) / 40) + 64);
     if (!rc) rc = ensure(c, c->pool, (tilesBound * 6144 + N * 192) / 16 + 1024 + planWgsMax * NB_POOL_PIECE);
     if (rc) return rc;
