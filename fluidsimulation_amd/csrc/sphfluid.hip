@@ -177,7 +177,7 @@ struct SphCtx {
     uint32_t *xhost = nullptr;      // pinned: own counters (4), headers received (8)
 
     // timings
-    bool timing = false;
+    int timing = 0; // SphConfig::enableTimings: 0 off, 1 every stage, 2 the neighbour kernels only
     std::vector<hipEvent_t> freeEvents;
     std::vector<EventPair> pending;
     SphTimings tm{};
@@ -231,7 +231,8 @@ struct StageTimer {
     bool on;
     hipStream_t s;
     StageTimer(SphCtx *ctx, int stage, hipStream_t stream = nullptr)
-        : c(ctx), on(ctx->timing), s(stream ? stream : ctx->stream)
+        : c(ctx), on(ctx->timing == 1 || (ctx->timing == 2 && (stage == SPH_T_DENSITY || stage == SPH_T_FORCE))),
+          s(stream ? stream : ctx->stream)
     {
         if (!on) return;
         for (hipEvent_t *e : {&ep.a, &ep.b}) {
@@ -723,7 +724,7 @@ int sph_create(const SphConfig *cfg, SphCtx **out)
         }
     }
     if (cfg && cfg->maxCells > 0) c->maxCells = std::max(cfg->maxCells, 64);
-    c->timing = cfg && cfg->enableTimings;
+    c->timing = cfg ? std::min(std::max(cfg->enableTimings, 0), 2) : 0;
     c->pinHost = cfg && cfg->pinHostArrays;
     *out = c;
     return SPH_OK;

@@ -173,7 +173,7 @@ class Context:
         """pin_host_arrays: SphConfig.pinHostArrays -- only with arrays that come back every frame
         and outlive the context (step_inplace), never with temporaries"""
         self.lib = load()
-        cfg = SphConfig(device, max_cells, 1 if timings else 0, 1 if pin_host_arrays else 0)
+        cfg = SphConfig(device, max_cells, int(timings), 1 if pin_host_arrays else 0)
         h = C.c_void_p()
         rc = self.lib.sph_create(C.byref(cfg), C.byref(h))
         if rc != SPH_OK:

@@ -467,6 +467,27 @@ def test_full_size_properties_c5(ctx, oracle):
     assert_close(gf[idx][core], forces[core], rtol=5e-5, what="force slab")
 
 
+def test_timing_modes():
+    """SphConfig.enableTimings: 1 times every stage, 2 the two neighbour kernels only (what
+    bench.py runs its timed region with), 0 nothing; the step count is kept either way"""
+    sc = jittered_block(8, 8, 8, seed=5)
+    p = native.make_params(sc.grid_size)
+    for mode, timed in ((1, {"sort", "table", "reorder", "density", "force", "integrate", "plan"}),
+                        (2, {"density", "force"}), (0, set())):
+        with native.Context(device=0, timings=mode) as c:
+            c.set_boundary(sc.bpos, sc.bparams)
+            c.upload(sc.pos, sc.vel, sc.inv_mass, sc.params, sc.grid_size)
+            c.step_resident(p, 3)
+            c.synchronize()
+            tm = c.timings()
+        assert tm["steps"] == 3
+        for k, ms in tm["ms"].items():
+            if k in timed:
+                assert ms > 0.0 and tm["launches"][k] >= 3, (mode, k)
+            elif k not in ("keys", "bodies"):
+                assert ms == 0.0 and tm["launches"][k] == 0, (mode, k)
+
+
 def test_stages_from_another_thread(ctx, oracle):
     """HIP's current device is per thread: a context created on one thread must work when the
     stages are called from another (Unity job threads)"""
