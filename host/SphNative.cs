@@ -82,7 +82,7 @@ public static unsafe class SphNative
     {
         public int device;
         public int maxCells;
-        public int enableTimings;
+        public int enableTimings;   // 0 off, 1 every stage, 2 the two neighbour kernels only
         public int pinHostArrays;
     }
 
