@@ -391,6 +391,11 @@ __device__ __forceinline__ void force_pair(const ForceTarget &t, const float4 &c
         d2 = (dx * dx + dy * dy) + dz * dz;
         a.cnt += (notSelf && d2 < t.thrF) ? 1 : 0;
         rinv = fminf(__builtin_amdgcn_rsqf(d2), 1.0e18f);
+        // two distinct particles at the same place: the reference's math.normalize(0) is 0 * inf,
+        // its pressure force -- and so the particle's force -- is NaN (FluidSPHByCPUSystem.cs:222).
+        // This variant reproduces that; the production variant returns the finite limit (the
+        // pair's pressure term is 0), see DESIGN.md section 2.
+        if (notSelf && d2 == 0.f) a.px = a.py = a.pz = __builtin_nanf("");
     } else {
         // tiny = 1e-30 keeps rsq finite for the pair (i, i) without a min: r = 1e-15, t = 1 and
         // both terms are multiplied by d = 0 / v_j - v_i = 0

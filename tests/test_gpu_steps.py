@@ -467,6 +467,35 @@ def test_full_size_properties_c5(ctx, oracle):
     assert_close(gf[idx][core], forces[core], rtol=5e-5, what="force slab")
 
 
+def test_coincident_particles(ctx, oracle):
+    """Two distinct particles at the same place (the wall colliders push particles into the same
+    tank corner, tools/tall_column.py): the reference's math.normalize(0) makes their forces NaN
+    (FluidSPHByCPUSystem.cs:222).  The exact-predicate variant reproduces that, NaN for the same
+    particles and the oracle's values everywhere else; the production variant returns the finite
+    limit for them (the pair's pressure term is 0) and the oracle's values everywhere else."""
+    sc = jittered_block(8, 8, 8, seed=31)
+    sc.pos[100] = sc.pos[37]          # two pairs, one of them with a third particle on top
+    sc.pos[200] = sc.pos[201]
+    sc.pos[202] = sc.pos[201]
+    dens, pres, cnt = oracle.density_pressure(sc.pos, sc.inv_mass, sc.params, sc.bpos, 1.0)
+    forces, fcnt = oracle.force(sc.pos, sc.inv_mass, sc.vel, sc.params, sc.bpos, sc.bparams,
+                                dens, pres, 1.0)
+    bad = np.zeros(sc.n, dtype=bool)
+    bad[[37, 100, 200, 201, 202]] = True
+    assert np.isnan(forces[bad]).all() and np.isfinite(forces[~bad]).all() and np.isfinite(dens).all()
+    for debug in (native.SPH_DEBUG_COUNTS, 0):
+        p = load_scene(ctx, sc, debug=debug)
+        run_to_force(ctx, p)
+        gd, gf = ctx.read(native.SPH_BUF_DENSITIES), ctx.read(native.SPH_BUF_FORCES)
+        assert_close(gd, dens, what="density")
+        assert_close(gf[~bad], forces[~bad], rtol=2e-5, what="force")
+        if debug:
+            np.testing.assert_array_equal(ctx.read(native.SPH_BUF_FORCE_COUNTS), fcnt)
+            assert np.isnan(gf[bad]).all()
+        else:
+            assert np.isfinite(gf[bad]).all()
+
+
 def test_timing_modes():
     """SphConfig.enableTimings: 1 times every stage, 2 the two neighbour kernels only (what
     bench.py runs its timed region with), 0 nothing; the step count is kept either way"""
