@@ -131,6 +131,7 @@ struct PlanShared {
     int4 cslot[SPH_TCELLS];   // per block cell: slices, first slot, first slot past the range, slots of list A
     int2 cwin[SPH_TCELLS][9]; // per cell and window: x = full slots | rest << 16 | tail in list A << 24,
                               //                      y = offset in list A | index in list B << 16
+    uint16_t slot16[NB_SLOTCAP]; // the block's slot table as it is built: record index | valid slices << 11
     uint32_t poolAt, poolEnd; // this workgroup's current piece of the pool (16-byte units)
     uint32_t listAt, listEnd; // this workgroup's current run of block-list entries
 };
@@ -249,8 +250,10 @@ template <int N> __device__ __forceinline__ void fold_slices(float (&v)[N], int 
     }
 }
 
-#ifdef NB_STAMPS // experimental builds: cycles per phase, summed over workgroups (thread 0)
+#if defined(NB_STAMPS) || defined(NB_PLAN_TRACE)
 static __device__ unsigned long long g_stamps[32];
+#endif
+#ifdef NB_STAMPS // experimental builds: cycles per phase, summed over workgroups (thread 0)
 #define NB_STAMP0() unsigned long long stamp_ = __builtin_amdgcn_s_memtime()
 #define NB_STAMP(i)                                                                              \
     do {                                                                                         \
@@ -263,6 +266,27 @@ static __device__ unsigned long long g_stamps[32];
 #else
 #define NB_STAMP0()
 #define NB_STAMP(i)
+#endif
+
+#ifdef NB_PLAN_TRACE // experimental builds: cycles per phase of the plan kernel, summed per wave in
+                     // registers and added to g_stamps once, at the end (no traffic while it runs)
+struct PlanTrace {
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+    __device__ __forceinline__ void start() { last = (uint32_t)__builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void mark(int i)
+    {
+        const uint32_t now = (uint32_t)__builtin_amdgcn_s_memtime();
+        acc[i] += now - last;
+        last = now;
+    }
+};
+#define PT_PARAM , PlanTrace &pt
+#define PT_ARG , pt
+#define PT_MARK(i) pt.mark(i)
+#else
+#define PT_PARAM
+#define PT_ARG
+#define PT_MARK(i)
 #endif
 
 // table look-ups for the 6x6x4 halo of the tile
@@ -297,7 +321,8 @@ __device__ __forceinline__ void tile_lookup_load(HaloRegs &r, int tile, const Nb
     const int tx = tile % g.ntx, t2 = tile / g.ntx, ty = t2 % g.nty, tz = t2 / g.nty;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const int c = (int)threadIdx.x + 64 * i;
+        int c = (int)threadIdx.x + 64 * i;
+        asm volatile("" : "+v"(c)); // (recomputed per tile, see plan_block)
         r.f[i] = r.b[i] = make_int2(0, 0);
         if (c < NB_HCELLS) {
             const int hx = c % NB_HX, hy = (c / NB_HX) % NB_HY, hz = c / (NB_HX * NB_HY);
@@ -583,11 +608,14 @@ struct ListAhead {
 // count | boundary count << 16.
 template <int sx, int sy, int sz>
 __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int tile, int bx0, int by0,
-                                           int bz0, ListAhead &la)
+                                           int bz0, ListAhead &la PT_PARAM)
 {
     constexpr int hxN = sx + 2, hyN = sy + 2, nh = hxN * hyN * (sz + 2), ncells = sx * sy * sz;
     static_assert(nh <= 3 * 64 && ncells <= 64, "three halo cells and one block cell per lane");
-    const int lane = threadIdx.x;
+    // (the lane's cell coordinates are recomputed for every block: hoisted out of the tile loop
+    // they are spilled, and a scratch reload is a load like any other -- see k_plan)
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
 
     // 1. records per halo cell (lane l: cells 3l .. 3l+2) and their places in the image
     int myf[3], rc[3];
@@ -605,6 +633,7 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
     const int rsum = rc[0] + rc[1] + rc[2];
     const int rincl = wave_incl_scan(rsum);
     const int total = __builtin_amdgcn_readlane(rincl, 63);
+    PT_MARK(2);
     if (total > A.cap) return false;
     const int rex[3] = {rincl - rsum, rincl - rsum + rc[0], rincl - rsum + rc[0] + rc[1]};
 #pragma unroll
@@ -631,7 +660,7 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
                 P = div_small(tcnt, per);
                 while (P * per < tcnt) P++;
             }
-            S = slices_for(per);
+            S = min(slices_for(per), 32); // (a tail's valid slices, < S, fit 5 bits)
 #pragma unroll
             for (int wi = 0; wi < 9; wi++) {
                 // first cell of the window in the tile's halo (rows of NB_HX cells)
@@ -656,6 +685,7 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
             uw = min(P, NB_MAXUNITS + 1) | (min(P * mw, 4095) << 12);
         }
     }
+    PT_MARK(3);
     const int tincl = wave_incl_scan(tcnt), uincl = wave_incl_scan(uw), sincl = wave_incl_scan(nsl);
     const int ttotal = __builtin_amdgcn_readlane(tincl, 63), ut = __builtin_amdgcn_readlane(uincl, 63),
               nslots = __builtin_amdgcn_readlane(sincl, 63);
@@ -707,6 +737,7 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
     idx = __builtin_amdgcn_readfirstlane(idx);
     if (lane < ncells && tcnt > 0) sh.cslot[lane] = make_int4(S, sex, sex + nsl, nA);
     wave_lds_fence();
+    PT_MARK(4);
 
     // 3. the plan goes straight to global memory: hinfo | units | slots
     if (off >= 0) {
@@ -714,10 +745,14 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
         UnitDesc *unitG = (UnitDesc *)(hinfoG + nh);
         uint32_t *slotG = (uint32_t *)(unitG + nunits);
 #pragma unroll
-        for (int i = 0; i < 3; i++)
-            if (3 * lane + i < nh)
-                hinfoG[3 * lane + i] = make_int4(rex[i], sh.h.fs[myf[i]],
-                                                 sh.h.fc[myf[i]] | (sh.h.bc[myf[i]] << 16), sh.h.bs[myf[i]]);
+        for (int i = 0; i < 3; i++) { // lane l writes cells l, l + 64, l + 128: whole lines per store
+            const int h = lane + 64 * i;
+            if (h < nh) {
+                const int hx = h % hxN, hy = (h / hxN) % hyN, hz = h / (hxN * hyN);
+                const int hf = tile_halo_index(bx0 + hx, by0 + hy, bz0 + hz);
+                hinfoG[h] = make_int4(sh.spref[h], sh.h.fs[hf], sh.h.fc[hf] | (sh.h.bc[hf] << 16), sh.h.bs[hf]);
+            }
+        }
         if (lane < ncells && tcnt > 0) {
             const int cstart = sh.h.fs[f], clds = sh.spref[fb];
 #pragma nounroll
@@ -735,8 +770,12 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
                 unitG[(uex & 0xfff) + part] = u;
             }
         }
+        PT_MARK(5);
         // one task per (cell, window): its slots of list A from the front of the cell's range,
-        // its tail slot of list B (if any) behind them
+        // its tail slot of list B (if any) behind them.  The table is built in LDS (16 bits an
+        // entry) and copied out 16 bytes per lane: as single dwords ~12 bytes apart from lane to
+        // lane it cost four times the write requests, which the reorder pass on the other stream
+        // -- the pair is bound by HBM bandwidth -- paid for.
         for (int t = lane; t < ncells * 9; t += NB_PTHREADS) {
             const int c = t / 9, wi = t - c * 9;
             const int2 cf = sh.cellf[c];
@@ -747,21 +786,34 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
             const int aoff = wdv.y & 0xffff, bidx = wdv.y >> 16;
             const int h0 = cf.y + ((wi / 3) - 1) * (hxN * hyN) + ((wi % 3) - 1) * hxN - 1;
             const int ws = sh.spref[h0], Sc = cs.x;
-            uint32_t *dst = slotG + cs.y + aoff;
+            uint16_t *dst = sh.slot16 + cs.y + aoff;
 #pragma nounroll
-            for (int j = 0; j < nfull; j++) dst[j] = (uint32_t)((ws + j * Sc) * 16);
+            for (int j = 0; j < nfull; j++) dst[j] = (uint16_t)(ws + j * Sc);
             if (rem) {
-                const uint32_t tail = (uint32_t)((ws + nfull * Sc) * 16);
-                if (tailA) dst[nfull] = tail;
-                else slotG[cs.y + cs.w + bidx] = tail | ((uint32_t)rem << 16);
+                const int tail = ws + nfull * Sc;
+                if (tailA) dst[nfull] = (uint16_t)tail;
+                else sh.slot16[cs.y + cs.w + bidx] = (uint16_t)(tail | (rem << 11));
             }
+        }
+        wave_lds_fence();
+        for (int q = lane; q * 4 < nslots; q += NB_PTHREADS) {
+            const uint2 v = *(const uint2 *)(sh.slot16 + 4 * q);
+            const uint32_t e[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
+            uint4 o;
+            o.x = ((e[0] & 0x7ffu) << 4) | ((e[0] >> 11) << 16);
+            o.y = ((e[1] & 0x7ffu) << 4) | ((e[1] >> 11) << 16);
+            o.z = ((e[2] & 0x7ffu) << 4) | ((e[2] >> 11) << 16);
+            o.w = ((e[3] & 0x7ffu) << 4) | ((e[3] >> 11) << 16);
+            ((uint4 *)slotG)[q] = o;
         }
         if (lane == 0)
             A.blockList[idx] =
                 make_int4(off, tile, nh | (nunits << 8) | (bx0 << 16) | (by0 << 20) | (bz0 << 24),
                           total | (ttotal << 11) | (nslots << 20));
     }
+    PT_MARK(6);
     wave_lds_fence(); // the LDS tables are reused by the next block
+    PT_MARK(7);
     return true;
 }
 
@@ -780,37 +832,53 @@ __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_
         }
     }
     la.tilesLeft = myTiles;
+#ifdef NB_PLAN_TRACE
+    PlanTrace pt;
+    pt.start();
+#endif
+    // This workgroup's tiles are tileList[blockIdx.x + k * gridDim.x]: lane l of a register holds
+    // the tile of round 64 c + l, loaded a chunk ahead, so that the loop has no load whose result
+    // it needs at once.  s_waitcnt vmcnt counts stores too (gfx950 has no separate store counter):
+    // any wait for a load in the middle of a tile also waits until every store of the tile before
+    // has drained, which takes far longer than the load (profiles: 45 % of the kernel).  The only
+    // place left where the wave waits for memory is the top of the loop.
+    const uint32_t grid = gridDim.x;
+    auto load_tiles = [&](uint32_t k0) -> int {
+        const uint64_t i = (uint64_t)blockIdx.x + (uint64_t)(k0 + threadIdx.x) * grid;
+        return i < ntiles ? (int)A.tileList[i] : 0;
+    };
+    int chunkCur = load_tiles(0), chunkNext = load_tiles(64);
     HaloRegs hr;
-    int tile = 0, tileNext = 0;
-    if (blockIdx.x < ntiles) {
-        tile = (int)A.tileList[blockIdx.x];
-        tile_lookup_load(hr, tile, A);
-        if (blockIdx.x + gridDim.x < ntiles) tileNext = (int)A.tileList[blockIdx.x + gridDim.x];
-    }
-    for (uint32_t ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+    if (blockIdx.x < ntiles) tile_lookup_load(hr, __builtin_amdgcn_readlane(chunkCur, 0), A);
+    uint32_t k = 0;
+    for (uint32_t ti = blockIdx.x; ti < ntiles; ti += grid, k++) {
         tile_lookup_store(sh.h, hr);
         wave_lds_fence();
-        const int tileCur = tile;
+        PT_MARK(0);
+        const int tileCur = __builtin_amdgcn_readlane(chunkCur, (int)(k & 63));
         la.tilesLeft--;
-        if (ti + gridDim.x < ntiles) { // the next tile's look-ups, and the index of the one after
-            tile = tileNext;
-            tile_lookup_load(hr, tile, A);
-            if (ti + 2 * gridDim.x < ntiles) tileNext = (int)A.tileList[ti + 2 * gridDim.x];
+        if (ti + grid < ntiles) { // the next tile's look-ups
+            if (((k + 1) & 63) == 0) {
+                chunkCur = chunkNext;
+                chunkNext = load_tiles(k + 1 + 64);
+            }
+            tile_lookup_load(hr, __builtin_amdgcn_readlane(chunkCur, (int)((k + 1) & 63)), A);
         }
+        PT_MARK(1);
         // The largest blocks whose 27-cell halo fits the LDS image: the whole tile (halo 144
         // cells for 32), else per y-half a 4x2x2 block (96 for 16), else per layer 4x2x1 (72 for
         // 8), 2x2x1 (48 for 4), single cells (27 for 1), else the global-memory path.  Blocks stay
         // long in x, the direction of the row windows.  One instantiation per shape.
-        if (plan_block<SPH_TX, SPH_TY, SPH_TZ>(sh, A, tileCur, 0, 0, 0, la)) continue;
+        if (plan_block<SPH_TX, SPH_TY, SPH_TZ>(sh, A, tileCur, 0, 0, 0, la PT_ARG)) continue;
         for (int yh = 0; yh < 2; yh++) {
-            if (plan_block<4, 2, 2>(sh, A, tileCur, 0, 2 * yh, 0, la)) continue;
+            if (plan_block<4, 2, 2>(sh, A, tileCur, 0, 2 * yh, 0, la PT_ARG)) continue;
             for (int z = 0; z < 2; z++) {
-                if (plan_block<4, 2, 1>(sh, A, tileCur, 0, 2 * yh, z, la)) continue;
+                if (plan_block<4, 2, 1>(sh, A, tileCur, 0, 2 * yh, z, la PT_ARG)) continue;
                 for (int xh = 0; xh < 2; xh++) {
-                    if (plan_block<2, 2, 1>(sh, A, tileCur, 2 * xh, 2 * yh, z, la)) continue;
+                    if (plan_block<2, 2, 1>(sh, A, tileCur, 2 * xh, 2 * yh, z, la PT_ARG)) continue;
                     for (int q = 0; q < 4; q++) {
                         const int bx = 2 * xh + (q & 1), by = 2 * yh + (q >> 1);
-                        if (plan_block<1, 1, 1>(sh, A, tileCur, bx, by, z, la)) continue;
+                        if (plan_block<1, 1, 1>(sh, A, tileCur, bx, by, z, la PT_ARG)) continue;
                         if (threadIdx.x == 0 && sh.h.fc[tile_halo_index(bx + 1, by + 1, z + 1)] > 0) {
                             const uint32_t idx = atomicAdd(&A.ctl[NB_CTL_GCELLS], 1u);
                             if (idx < (uint32_t)A.gcellCap) A.gcellList[idx] = make_int2(tileCur, bx | (by << 8) | (z << 16));
@@ -822,6 +890,10 @@ __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_
         }
         wave_lds_fence(); // sh.h is rewritten by the next tile
     }
+#ifdef NB_PLAN_TRACE
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_stamps[i], (unsigned long long)pt.acc[i]);
+#endif
     // the unused entries of this workgroup's last run of the block list: empty blocks
     if (threadIdx.x == 0) {
         for (uint32_t i = sh.listAt; i < sh.listEnd; i++)
@@ -843,6 +915,7 @@ template <bool FORCE, bool COUNT> struct NbShared {
     uint32_t next;
 };
 static_assert(sizeof(HaloTab) <= NB_PLANMAX, "the global-memory path keeps the tile's halo in the plan area");
+static_assert(NB_CAP < 2048, "PlanShared::slot16 holds record indices in 11 bits");
 
 // one planned block
 template <bool FORCE, bool COUNT>

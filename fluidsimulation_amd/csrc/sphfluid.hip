@@ -735,11 +735,11 @@ int sph_destroy(SphCtx *c)
     if (!c) return SPH_E_INVALID;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-#ifdef NB_STAMPS
+#if defined(NB_STAMPS) || defined(NB_PLAN_TRACE)
     {
         unsigned long long h[32];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)) == hipSuccess) {
-            const char *pn[8] = {"lookup", "sizes", "scan", "alloc+offsets", "tmat+tables", "wait", "copy-out", "-"};
+            const char *pn[8] = {"tile-start (wait for look-ups, LDS store)", "prefetch issue + next tile index", "records", "cells+windows", "scans+alloc", "hinfo+units", "slots+list", "end fence"};
             const char *en[8] = {"plan-dma", "rec-issue", "rec-wait", "units", "units-wait", "-", "-", "-"};
             for (int k = 0; k < 3; k++) {
                 double tot = 0;
