@@ -506,17 +506,21 @@ template <bool FORCE> __device__ __forceinline__ void loop_constants(const Mat &
     k = FORCE ? m.negInvH : m.negInvH2;
     thr = FORCE ? m.thrF : m.h2;
 }
-// finishing constants of target gi with material index mi (see Pass)
-template <bool FORCE, bool COUNT>
-__device__ __forceinline__ float4 finish_constants(const NbArgs &A, int gi, uint32_t mi)
+// what the finishing constants of a target are made of, per material (NbShared::mfin):
+//   density: -, m*315/(64 pi h^9) [* h2^3 in the production variant], k, rho0;  force: h, spiky, mu, -
+template <bool FORCE, bool COUNT> __device__ __forceinline__ float4 finish_row(const Mat *m)
 {
-    const Mat *m = A.mats + mi;
+    if (FORCE) return make_float4(m->h, m->spiky, m->viscosity, 0.f);
+    return make_float4(0.f, COUNT ? m->poly6 : m->poly6h6, m->gasConstant, m->restDensity);
+}
+// finishing constants of a target (see Pass) from its material's row and, force pass, its density d
+template <bool FORCE> __device__ __forceinline__ float4 finish_constants(const float4 &row, float d)
+{
     if (FORCE) {
-        const float d = A.rhoIn[gi];
-        const float h = m->h, spiky = m->spiky, mu = m->viscosity;
+        const float h = row.x, spiky = row.y, mu = row.z;
         return make_float4(0.f, d * spiky * (h * h), mu / d * spiky * h, d);
     }
-    return make_float4(0.f, COUNT ? m->poly6 : m->poly6h6, m->gasConstant, m->restDensity);
+    return row;
 }
 
 // floor(a / b) for 0 <= a < 2^20, 1 <= b <= 64 without an integer division: (a + 0.5) / b is at
@@ -548,7 +552,7 @@ __device__ void process_cell_global(const HaloTab &sh, const NbArgs &A, int lx, 
         float tkv, thr;
         const uint32_t mi = A.mat[ti];
         loop_constants<FORCE>(A.mats[mi], tkv, thr);
-        const float4 fc4 = finish_constants<FORCE, COUNT>(A, ti, mi);
+        const float4 fc4 = finish_constants<FORCE>(finish_row<FORCE, COUNT>(A.mats + mi), FORCE ? A.rhoIn[ti] : 0.f);
         const float4 tp = A.posm[ti];
         ps.t.x = tp.x; ps.t.y = tp.y; ps.t.z = tp.z;
         if constexpr (FORCE) {
@@ -911,14 +915,17 @@ template <bool FORCE, bool COUNT> struct NbShared {
     float4 recP[NB_CAP + 1];             // x, y, z, m_j (+ the FAR record)
     float4 recV[FORCE ? NB_CAP + 1 : 1]; // vx, vy, vz, q_j = p_j/rho_j^2
     float4 mtab[NB_MTAB];                // per material: -1/h2, -1/h, h2, thrF
+    float4 mfin[NB_MTAB];                // per material: finish_row
     BlockHdr hdr[NB_CHUNK];
     uint32_t next;
 };
 static_assert(sizeof(HaloTab) <= NB_PLANMAX, "the global-memory path keeps the tile's halo in the plan area");
 static_assert(NB_CAP < 2048, "PlanShared::slot16 holds record indices in 11 bits");
 
-// one planned block
-template <bool FORCE, bool COUNT>
+// one planned block.  MULTI: the scene has more than one material (else no target's material index
+// is loaded: with a load on any path of the unit loop, the compiler's wait for it at the loop head
+// would make every unit wait for the stores of the unit before)
+template <bool FORCE, bool COUNT, bool MULTI>
 __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbArgs &A, const BlockHdr hdr,
                                            bool request, uint32_t chunk, uint32_t &pending)
 {
@@ -978,14 +985,22 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
         recP[NB_CAP] = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f); // what masked lanes read
         if (FORCE) recV[NB_CAP] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // material index of this wave's first unit (the later ones are fetched one unit ahead)
-    uint32_t miNext = 0;
+    // What a unit needs from global memory -- the targets' material indices (only with more than
+    // one material), force pass: their densities and the lanes' first hit-mask words -- is
+    // fetched one unit ahead, the first unit's here: a wait for a load in the middle of a unit
+    // would also wait for the unit's stores (vmcnt counts both).
+    const bool walkMasks = FORCE && !COUNT && A.useMasks;
+    uint32_t miNext = 0, m0Next = 0;
+    float rhoNext = 0.f;
     if (w < nunits) {
         const UnitDesc u0 = units[w];
         const int T0 = u0.tS & 0xff, S0 = u0.tS >> 8;
         int u, sl;
         split_lane(lane, S0, u, sl);
-        miNext = A.mat[u0.gi0 + (u < T0 ? u : 0)];
+        const int t0 = u0.gi0 + (u < T0 ? u : 0);
+        if constexpr (MULTI) miNext = A.mat[t0];
+        if (FORCE) rhoNext = A.rhoIn[t0];
+        if (walkMasks) m0Next = maskBlk[(size_t)u0.maskw * 64 + lane];
     }
     NB_STAMP((FORCE ? 16 : 8) + 1);
     __syncthreads();
@@ -1011,24 +1026,28 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
         const int ti = ud.gi0 + tloc;
         const bool writer = active && slice == 0;
         Pass<FORCE, COUNT> ps;
-        const uint32_t mi = miNext;
-        if (unit + NB_WAVES < nunits) { // the next unit's material indices, used one unit later
+        const uint32_t mi = MULTI ? miNext : 0u, m0 = m0Next;
+        const float rhoi = rhoNext;
+        if (unit + NB_WAVES < nunits) { // the next unit's, used one unit later
             const UnitDesc un = units[unit + NB_WAVES];
             const int Tn = un.tS & 0xff, Sn = un.tS >> 8;
             int u2, sl2;
             split_lane(lane, Sn, u2, sl2);
-            miNext = A.mat[un.gi0 + (u2 < Tn ? u2 : 0)];
+            const int tn = un.gi0 + (u2 < Tn ? u2 : 0);
+            if constexpr (MULTI) miNext = A.mat[tn];
+            if (FORCE) rhoNext = A.rhoIn[tn];
+            if (walkMasks) m0Next = maskBlk[(size_t)un.maskw * 64 + lane];
         }
-        // the target's finishing constants come from global memory (all slices of a target read
-        // the same words): loaded now, used after the walk
-        const float4 fc4 = finish_constants<FORCE, COUNT>(A, ti, mi);
-        float4 mt;
+        float4 mt, mf;
         if (mi < NB_MTAB) {
             mt = sh.mtab[mi];
+            mf = sh.mfin[mi];
         } else {
             const Mat *m = A.mats + mi;
             mt = make_float4(m->negInvH2, m->negInvH, m->h2, m->thrF);
+            mf = finish_row<FORCE, COUNT>(m);
         }
+        const float4 fc4 = finish_constants<FORCE>(mf, rhoi);
         {
             const float4 tp = *(const float4 *)(baseP + self16);
             ps.t.x = tp.x; ps.t.y = tp.y; ps.t.z = tp.z;
@@ -1047,13 +1066,13 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
         constexpr int G = FORCE ? NB_FG : NB_DG; // slots per iteration
         // hit masks of the unit: one word per 32 slots (list A, then list B) and lane
         uint32_t *maskU = maskBlk + (size_t)ud.maskw * 64 + lane;
-        if (FORCE && !COUNT && A.useMasks) {
+        if (walkMasks) {
             // Force pass over the hits the density pass found: every lane walks the set bits of
             // its own words (bit i of word j = slot 32 j + i of the unit); lanes that have run
             // out of hits are switched off, the wave goes on until its longest list ends.  A
             // candidate the density pass left out is farther than h: its force terms are 0.
             const int nwords = (nA + nB + 31) >> 5;
-            uint32_t m = __builtin_bitreverse32(maskU[0]);
+            uint32_t m = __builtin_bitreverse32(m0);
             const char *sbase = slots + ud.slotA * 4;
             for (int j = 0; j < nwords; j++, sbase += 128) {
                 uint32_t mnext = 0;
@@ -1152,7 +1171,7 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
 // would cost most of a millisecond per launch by itself); the next chunk is requested while the
 // current one is being processed.  Then the cells of the global-memory path, one at a time, dealt
 // the same way.
-template <bool FORCE, bool COUNT>
+template <bool FORCE, bool COUNT, bool MULTI>
 // second launch bound = waves per SIMD the register allocation must allow (what the LDS allows)
 __global__ __launch_bounds__(FORCE ? NB_FTHREADS : NB_DTHREADS)
 __attribute__((amdgpu_waves_per_eu((FORCE ? NB_FLB : NB_DLB) - (COUNT ? 1 : 0), (FORCE ? NB_FLB : NB_DLB) - (COUNT ? 1 : 0))))
@@ -1163,6 +1182,7 @@ void k_neighbors(NbArgs A)
     for (int i = tid; i < NB_MTAB && i < A.nmats; i += blockDim.x) {
         const Mat *m = A.mats + i;
         sh.mtab[i] = make_float4(m->negInvH2, m->negInvH, m->h2, m->thrF);
+        sh.mfin[i] = finish_row<FORCE, COUNT>(m);
     }
     const uint32_t nblocks = min(A.ctl[NB_CTL_BLOCKS], (uint32_t)A.blockCap);
     // blocks per request: NB_CHUNK when there is plenty of work, fewer when the whole list is only
@@ -1183,7 +1203,7 @@ void k_neighbors(NbArgs A)
         for (uint32_t i = 0; i < n; i++) {
             const BlockHdr hdr = sh.hdr[i];
             if (hdr.w == 0) continue; // unused list entry
-            exec_block<FORCE, COUNT>(sh, A, hdr, !requested, chunk, pending);
+            exec_block<FORCE, COUNT, MULTI>(sh, A, hdr, !requested, chunk, pending);
             requested = true;
         }
         if (!requested && tid == 0) pending = atomicAdd(&A.ctl[A.queue], chunk) + gridDim.x * chunk;

@@ -129,7 +129,7 @@ struct SphCtx {
     bool gridExplicit = false, gridValid = false;
     DevBuf<int2> table, btable, ttable;
     DevBuf<uint32_t> tileList, tileCtl; // non-empty tiles; NB_CTL_* words and work-queue counters
-    int nbGrid[4] = {0, 0, 0, 0};        // persistent grid of k_neighbors<FORCE,COUNT>
+    int nbGrid[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // persistent grid of k_neighbors<FORCE,COUNT,MULTI>
     int queueNext = NB_CTL_QUEUE0;       // next unused pair of work-queue words of tileCtl
     // neighbour plan (k_plan): block list, plans, cells of the global-memory path
     DevBuf<BlockHdr> blockList;
@@ -1212,13 +1212,13 @@ static int ensure_plan(SphCtx *c, const SphParams *p, hipStream_t stream = nullp
 
 // launches k_neighbors<FORCE,COUNT> as persistent workgroups: as many as the chip holds at once
 extern "C++" {
-template <bool FORCE, bool COUNT> static int launch_neighbors(SphCtx *c, NbArgs &A)
+template <bool FORCE, bool COUNT, bool MULTI> static int launch_neighbors_m(SphCtx *c, NbArgs &A)
 {
     constexpr int threads = FORCE ? NB_FTHREADS : NB_DTHREADS;
-    int &grid = c->nbGrid[(FORCE ? 2 : 0) + (COUNT ? 1 : 0)];
+    int &grid = c->nbGrid[(FORCE ? 2 : 0) + (COUNT ? 1 : 0) + (MULTI ? 4 : 0)];
     if (grid == 0) {
         int perCU = 0;
-        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_neighbors<FORCE, COUNT>,
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_neighbors<FORCE, COUNT, MULTI>,
                                                                threads, 0));
         grid = std::max(1, perCU) * std::max(1, c->prop.multiProcessorCount);
     }
@@ -1231,9 +1231,14 @@ template <bool FORCE, bool COUNT> static int launch_neighbors(SphCtx *c, NbArgs 
     }
     A.queue = c->queueNext;
     c->queueNext += 2; // blocks, cells of the global-memory path
-    k_neighbors<FORCE, COUNT><<<std::min(grid, std::max(c->grid.tiles, 1)), threads, 0, c->stream>>>(A);
+    k_neighbors<FORCE, COUNT, MULTI><<<std::min(grid, std::max(c->grid.tiles, 1)), threads, 0, c->stream>>>(A);
     HIPCHK(c, hipGetLastError());
     return SPH_OK;
+}
+// (one instantiation for scenes with a single material, one for the others: see exec_block)
+template <bool FORCE, bool COUNT> static int launch_neighbors(SphCtx *c, NbArgs &A)
+{
+    return A.nmats > 1 ? launch_neighbors_m<FORCE, COUNT, true>(c, A) : launch_neighbors_m<FORCE, COUNT, false>(c, A);
 }
 } // extern "C++"
 
