@@ -990,7 +990,7 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
     // fetched one unit ahead, the first unit's here: a wait for a load in the middle of a unit
     // would also wait for the unit's stores (vmcnt counts both).
     const bool walkMasks = FORCE && !COUNT && A.useMasks;
-    uint32_t miNext = 0, m0Next = 0;
+    uint32_t miNext = 0, m0Next = 0, m1Next = 0; // (m0, m1: the lane's first two hit-mask words)
     float rhoNext = 0.f;
     if (w < nunits) {
         const UnitDesc u0 = units[w];
@@ -1000,7 +1000,10 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
         const int t0 = u0.gi0 + (u < T0 ? u : 0);
         if constexpr (MULTI) miNext = A.mat[t0];
         if (FORCE) rhoNext = A.rhoIn[t0];
-        if (walkMasks) m0Next = maskBlk[(size_t)u0.maskw * 64 + lane];
+        if (walkMasks) {
+            m0Next = maskBlk[(size_t)u0.maskw * 64 + lane];
+            if ((u0.nAB & 0xffff) + (u0.nAB >> 16) > 32) m1Next = maskBlk[(size_t)u0.maskw * 64 + 64 + lane];
+        }
     }
     NB_STAMP((FORCE ? 16 : 8) + 1);
     __syncthreads();
@@ -1026,7 +1029,7 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
         const int ti = ud.gi0 + tloc;
         const bool writer = active && slice == 0;
         Pass<FORCE, COUNT> ps;
-        const uint32_t mi = MULTI ? miNext : 0u, m0 = m0Next;
+        const uint32_t mi = MULTI ? miNext : 0u, m0 = m0Next, m1 = m1Next;
         const float rhoi = rhoNext;
         if (unit + NB_WAVES < nunits) { // the next unit's, used one unit later
             const UnitDesc un = units[unit + NB_WAVES];
@@ -1036,7 +1039,10 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
             const int tn = un.gi0 + (u2 < Tn ? u2 : 0);
             if constexpr (MULTI) miNext = A.mat[tn];
             if (FORCE) rhoNext = A.rhoIn[tn];
-            if (walkMasks) m0Next = maskBlk[(size_t)un.maskw * 64 + lane];
+            if (walkMasks) {
+                m0Next = maskBlk[(size_t)un.maskw * 64 + lane];
+                if ((un.nAB & 0xffff) + (un.nAB >> 16) > 32) m1Next = maskBlk[(size_t)un.maskw * 64 + 64 + lane];
+            }
         }
         float4 mt, mf;
         if (mi < NB_MTAB) {
@@ -1075,8 +1081,9 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
             uint32_t m = __builtin_bitreverse32(m0);
             const char *sbase = slots + ud.slotA * 4;
             for (int j = 0; j < nwords; j++, sbase += 128) {
-                uint32_t mnext = 0;
-                if (j + 1 < nwords) mnext = maskU[(j + 1) * 64];
+                uint32_t mnext = 0; // (word 1 came with word 0, a unit ahead; units of more than
+                                    // 64 slots -- crowded cells -- load the rest here)
+                if (j + 1 < nwords) mnext = j == 0 ? m1 : maskU[(j + 1) * 64];
                 while (m) {
                     const int bit = __builtin_ctz(m);
                     m &= m - 1;
