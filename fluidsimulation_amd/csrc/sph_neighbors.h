@@ -455,8 +455,8 @@ template <bool COUNT> struct Pass<false, COUNT> {
         density_pair<COUNT>(t, cp, acc, cnt, hits);
     }
     // folds the slices and writes rho, p, q for target ti
-    __device__ __forceinline__ void finish(const NbArgs &A, int S, int slice, bool writer, int ti,
-                                           const float4 &fc4)
+    __device__ __forceinline__ float4 finish(const NbArgs &A, int S, int slice, bool writer, int ti,
+                                             const float4 &fc4)
     {
         float v[1] = {acc};
         int c2 = cnt;
@@ -472,6 +472,7 @@ template <bool COUNT> struct Pass<false, COUNT> {
             A.velq[ti].w = pressure * __builtin_amdgcn_rcpf(density * density);
             if (COUNT) A.counts[ti] = c2;
         }
+        return make_float4(0.f, 0.f, 0.f, 0.f);
     }
 };
 
@@ -483,20 +484,18 @@ template <bool COUNT> struct Pass<true, COUNT> {
     {
         force_pair<COUNT>(t, cp, cv, notSelf, a);
     }
-    __device__ __forceinline__ void finish(const NbArgs &A, int S, int slice, bool writer, int ti,
-                                           const float4 &fc4)
+    // (the force itself is returned, not stored: exec_block stores it one unit later, see there)
+    __device__ __forceinline__ float4 finish(const NbArgs &A, int S, int slice, bool writer, int ti,
+                                             const float4 &fc4)
     {
         float v[3] = {fc4.y * a.px + fc4.z * a.vx, fc4.y * a.py + fc4.z * a.vy, fc4.y * a.pz + fc4.z * a.vz};
         int c2 = a.cnt;
         fold_slices<3>(v, c2, S, slice);
-        if (writer) {
-            const float fx = v[0], fy = v[1], fz = v[2];
-            // forces = forcePressure + forceViscosity + gravity * rho_i  (:140,:202)
-            const float trho = fc4.w;
-            A.force[ti] =
-                make_float4(fx + A.gx * trho, fy + A.gy * trho, fz + A.gz * trho, 0.f);
-            if (COUNT) A.counts[ti] = c2;
-        }
+        const float fx = v[0], fy = v[1], fz = v[2];
+        // forces = forcePressure + forceViscosity + gravity * rho_i  (:140,:202)
+        const float trho = fc4.w;
+        if (COUNT && writer) A.counts[ti] = c2;
+        return make_float4(fx + A.gx * trho, fy + A.gy * trho, fz + A.gz * trho, 0.f);
     }
 };
 
@@ -592,7 +591,8 @@ __device__ void process_cell_global(const HaloTab &sh, const NbArgs &A, int lx, 
                 }
             }
         }
-        ps.finish(A, S, slice, active && slice == 0, ti, fc4);
+        const float4 F = ps.finish(A, S, slice, active && slice == 0, ti, fc4);
+        if (FORCE && active && slice == 0) A.force[ti] = F;
     }
 }
 
@@ -1016,6 +1016,11 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
     const char *baseP = (const char *)recP, *baseV = (const char *)recV;
     const char *slots = (const char *)sh.plan + oSlots;
     const int far16 = NB_CAP * 16;
+    // Force pass: a unit's forces are stored at the head of the NEXT unit, behind that unit's loads
+    // for the one after.  The wait for those loads at the head of a unit is vmcnt(0), which waits
+    // for stores as well: stored at its end, a unit's forces were what the next unit waited for.
+    float4 heldF = make_float4(0.f, 0.f, 0.f, 0.f);
+    int heldTi = -1;
     for (int unit = w; unit < nunits; unit += NB_WAVES) {
         const UnitDesc ud = units[unit];
         const int tS = uniform_i(ud.tS), nAB = uniform_i(ud.nAB);
@@ -1044,6 +1049,7 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
                 if ((un.nAB & 0xffff) + (un.nAB >> 16) > 32) m1Next = maskBlk[(size_t)un.maskw * 64 + 64 + lane];
             }
         }
+        if (FORCE && heldTi >= 0) A.force[heldTi] = heldF;
         float4 mt, mf;
         if (mi < NB_MTAB) {
             mt = sh.mtab[mi];
@@ -1165,8 +1171,10 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
             }
             if (g & 31) flush(g & 31);
         }
-        ps.finish(A, S2, slice, writer, ti, fc4);
+        heldF = ps.finish(A, S2, slice, writer, ti, fc4);
+        heldTi = writer ? ti : -1;
     }
+    if (FORCE && heldTi >= 0) A.force[heldTi] = heldF;
     NB_STAMP((FORCE ? 16 : 8) + 3);
     lds_barrier(); // the LDS image and the plan are reused by the next block
     NB_STAMP((FORCE ? 16 : 8) + 4);
