@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--config", default="C3", choices=list(scene.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-round-trip", action="store_true")
+    ap.add_argument("--no-stage-breakdown", action="store_true",
+                    help="skip the second pass that times the stages other than the neighbour kernels")
     ap.add_argument("--cpu-baseline-config", default=None,
                     help="workload of the bounded CPU sample (default: same as --config)")
     return ap.parse_args()
@@ -210,7 +212,7 @@ def main():
         ms_step = elapsed / a.steps * 1e3
         # density and force: HIP events on the library's stream over the timed region itself
         stage_ms = {k: tm["ms"][k] / max(tm["steps"], 1) for k in tm["ms"]}
-        if sim is None:
+        if sim is None and not a.no_stage_breakdown:
             # the other stages: a second pass of the same run with every stage timed (the events
             # of all nine stages put a bubble between every two kernels, 1.4 % of a C3 step, which
             # the timed region should not pay)
