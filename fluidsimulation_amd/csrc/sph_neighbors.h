@@ -726,7 +726,10 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
         }
         const uint32_t o = sh.poolAt, i = sh.listAt;
         const bool ok = o + units16 <= A.poolCap && i < (uint32_t)A.blockCap;
-        if (!ok) atomicOr(&A.ctl[NB_CTL_ERROR], 1u);
+        if (!ok) { // no room: the entry (if it exists) is marked empty, the host sees the flag
+            atomicOr(&A.ctl[NB_CTL_ERROR], 1u);
+            if (i < (uint32_t)A.blockCap) A.blockList[i] = make_int4(0, 0, 0, 0);
+        }
         sh.poolAt += units16;
         sh.listAt += 1;
         const int left = (int)(sh.listEnd - sh.listAt);

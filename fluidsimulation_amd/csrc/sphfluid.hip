@@ -121,8 +121,9 @@ struct SphCtx {
     // SphConfig.pinHostArrays: caller arrays registered with the driver (page-locked) on first
     // use and kept, so that the per-frame copies of the host round trips run as DMA at PCIe rate
     bool pinHost = false;
-    struct Pinned { const void *p; size_t bytes; };
+    struct Pinned { const void *p; size_t bytes /* registered, 0 = registration failed */, asked; };
     std::vector<Pinned> pinned;
+    int pinOk = 0, pinFailed = 0;
 
     // grid
     GridDesc grid{};
@@ -138,6 +139,7 @@ struct SphCtx {
     bool havePlan = false;
     bool haveMasks = false; // the production density pass has run on this plan
     int fallbackCap = -1; // debug: LDS record cap override for the neighbour kernels
+    long long poolLimit = 0; // debug (SPHFLUID_POOL_LIMIT, 16-byte units): cap on the plan pool, for the overflow test
 
     // boundary
     int nb = 0;
@@ -708,6 +710,9 @@ int sph_create(const SphConfig *cfg, SphCtx **out)
                        hipEventCreateWithFlags(&c->evPlan, hipEventDisableTiming) != hipSuccess)) {
         (void)hipStreamDestroy(c->stream2);
         c->stream2 = nullptr;
+        if (c->evTable) (void)hipEventDestroy(c->evTable);
+        if (c->evPlan) (void)hipEventDestroy(c->evPlan);
+        c->evTable = c->evPlan = nullptr;
     }
     if (dev < SPH_MAX_DEVICES) { // this device's copy of `scratch` (device `dev` is current)
         std::lock_guard<std::mutex> lk(g_scratchLock);
@@ -716,6 +721,9 @@ int sph_create(const SphConfig *cfg, SphCtx **out)
             const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
             if (e != hipSuccess || !ptr) {
                 (void)hipStreamDestroy(c->stream);
+                if (c->stream2) (void)hipStreamDestroy(c->stream2);
+                if (c->evTable) (void)hipEventDestroy(c->evTable);
+                if (c->evPlan) (void)hipEventDestroy(c->evPlan);
                 delete c;
                 return fail(nullptr, SPH_E_DEVICE, "hipGetSymbolAddress(scratch): %s",
                             hipGetErrorString(e));
@@ -726,6 +734,7 @@ int sph_create(const SphConfig *cfg, SphCtx **out)
     if (cfg && cfg->maxCells > 0) c->maxCells = std::max(cfg->maxCells, 64);
     c->timing = cfg ? std::min(std::max(cfg->enableTimings, 0), 2) : 0;
     c->pinHost = cfg && cfg->pinHostArrays;
+    if (const char *e = getenv("SPHFLUID_POOL_LIMIT")) c->poolLimit = atoll(e);
     *out = c;
     return SPH_OK;
 }
@@ -939,28 +948,68 @@ int sph_get_grid(SphCtx *c, SphGrid *g)
 }
 
 // Registers a caller array with the driver once (SphConfig.pinHostArrays) and remembers it; a
-// failure is not an error, the copy then runs from pageable memory as before.  At most 16 arrays
-// are kept, the oldest is released first.
+// failure is not an error -- the copy then runs from pageable memory as before -- but it is counted
+// (sph_pin_stats).  An array that comes back with ANY other size is registered afresh: the host may
+// have freed and reallocated it, and a smaller mapping at the same address has other pages.  At
+// most 16 arrays are kept, the oldest is released first.
 static void pin_host(SphCtx *c, const void *p, size_t bytes)
 {
     if (!c->pinHost || !p || bytes < (1u << 20)) return;
+    auto reg = [&](size_t n) -> size_t {
+        if (hipHostRegister(const_cast<void *>(p), n, hipHostRegisterDefault) == hipSuccess) {
+            c->pinOk++;
+            return n;
+        }
+        (void)hipGetLastError();
+        c->pinFailed++;
+        return 0;
+    };
     for (auto &e : c->pinned)
         if (e.p == p) {
-            if (e.bytes >= bytes) return;
-            (void)hipHostUnregister(const_cast<void *>(p));
-            e.bytes = 0;
-            if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) e.bytes = bytes;
-            else (void)hipGetLastError();
+            if (e.bytes == bytes || (e.bytes == 0 && e.asked == bytes)) return; // (a failure is not retried every frame)
+            if (e.bytes) (void)hipHostUnregister(const_cast<void *>(p));
+            e.bytes = reg(bytes);
+            e.asked = bytes;
             return;
         }
     if (c->pinned.size() >= 16) {
         if (c->pinned.front().bytes) (void)hipHostUnregister(const_cast<void *>(c->pinned.front().p));
         c->pinned.erase(c->pinned.begin());
     }
-    size_t got = 0;
-    if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) got = bytes;
-    else (void)hipGetLastError();
-    c->pinned.push_back({p, got});
+    c->pinned.push_back({p, reg(bytes), bytes});
+}
+
+// Releases the registration of one caller array (p) or of all of them (p == NULL).  A host that
+// frees or reallocates an array it has passed to a context with pinHostArrays set calls this first:
+// freeing registered memory is undefined, and a new mapping at the same address has other pages.
+int sph_unpin_host(SphCtx *c, const void *p)
+{
+    if (!c) return SPH_E_INVALID;
+    if (int rc_ = use_device(c)) return rc_;
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // no copy may still be using the pages
+    for (size_t i = 0; i < c->pinned.size();) {
+        if (!p || c->pinned[i].p == p) {
+            if (c->pinned[i].bytes && hipHostUnregister(const_cast<void *>(c->pinned[i].p)) != hipSuccess)
+                (void)hipGetLastError();
+            c->pinned.erase(c->pinned.begin() + (long)i);
+        } else {
+            i++;
+        }
+    }
+    return SPH_OK;
+}
+
+// stats[0] = arrays registered at the moment, [1] = registrations that succeeded, [2] = that failed
+// (the copies of those arrays ran from pageable memory), since sph_create
+int sph_pin_stats(SphCtx *c, int32_t stats[3])
+{
+    if (!c || !stats) return SPH_E_INVALID;
+    int live = 0;
+    for (const auto &e : c->pinned) live += e.bytes ? 1 : 0;
+    stats[0] = live;
+    stats[1] = c->pinOk;
+    stats[2] = c->pinFailed;
+    return SPH_OK;
 }
 
 int sph_upload(SphCtx *c, const float *pos, const float *vel, const float *invMass,
@@ -1186,24 +1235,35 @@ static int ensure_plan(SphCtx *c, const SphParams *p, hipStream_t stream = nullp
     if (c->havePlan) return SPH_OK;
     if (!stream) stream = c->stream;
     if (c->mats.size() > 65535) return fail(c, SPH_E_TOOLARGE, "more than 65535 distinct materials");
-    // sizes: a block has at least one target and a tile at most 32 blocks; a cell takes the
-    // global-memory path only if more than NB_CAP records lie in its 27 cells; a plan is at most
-    // 2.4 KB of halo table per block plus ~40 bytes per target and ~1 byte per record; the hit
-    // masks take 32 bytes per target when a cell's targets fill a wave, up to ~4x that in sparse cells
+    // Sizes.  Block list: a block has at least one target and a tile at most 32 blocks.  Global-
+    // memory path: a cell takes it only if more than NB_CAP records lie in its 27 cells.  Pool, in
+    // bytes: per non-empty tile the halo table (2304 B for a whole-tile block; a tile that falls
+    // into single-cell blocks, 432 B each, holds hundreds of particles and is covered by their
+    // share); per non-empty cell one unit (32 B), one hit-mask word for its 64 lanes (256 B) and
+    // nine windows' slots -- a lattice with one particle per cell needs exactly that, 330 B per
+    // particle; per particle beyond that ~37 B of masks (one bit per lane and slot) and ~14 B of
+    // slots at eight per cell, more in the sparse cells the per-cell term already pays for.
     const size_t N = (size_t)c->n, tiles = (size_t)c->grid.tiles;
-    const size_t tilesBound = std::min(tiles, N);
-    const size_t planWgsMax = NB_PLAN_WGS_PER_CU * (size_t)std::max(1, c->prop.multiProcessorCount);
+    const size_t tilesBound = std::min(tiles, N), cellsBound = std::min((size_t)c->grid.cells, N);
+    // persistent single-wave workgroups (each takes its pieces of the pool and of the list)
+    const int planWgs = NB_PLAN_WGS_PER_CU * std::max(1, c->prop.multiProcessorCount);
+    const int grid = std::max(1, std::min((int)std::min<size_t>(tilesBound, 1u << 30), planWgs));
     // (+ two entries per tile: a plan workgroup's runs of the list have one entry per tile it has
     // still to plan, and a tile without fluid targets leaves its entry unused)
-    int rc = ensure(c, c->blockList, std::min(tilesBound * 32, N) + 2 * tilesBound + 64 + planWgsMax * (NB_LIST_PIECE + 2));
+    const BlockHdr *listWas = c->blockList.p;
+    int rc = ensure(c, c->blockList, std::min(tilesBound * 32, N) + 2 * tilesBound + 64 + (size_t)grid * (NB_LIST_PIECE + 2));
+    // (an entry the plan could not fill is written as empty by the plan itself; the rest of a fresh
+    // list must not look like blocks either)
+    if (!rc && c->blockList.p != listWas)
+        HIPCHK(c, hipMemsetAsync(c->blockList.p, 0, c->blockList.cap * sizeof(BlockHdr), stream));
     if (!rc) rc = ensure(c, c->gcellList, (c->fallbackCap >= 0 ? N : (N + (size_t)c->nb) / 40) + 64);
-    if (!rc) rc = ensure(c, c->pool, (tilesBound * 6144 + N * 192) / 16 + 1024 + planWgsMax * NB_POOL_PIECE);
+    size_t poolUnits = (tilesBound * 2560 + cellsBound * 352 + N * 128) / 16 + 1024 + (size_t)grid * NB_POOL_PIECE;
+    if (c->poolLimit > 0) poolUnits = std::min<size_t>(poolUnits, (size_t)c->poolLimit); // (tests)
+    if (!rc) rc = ensure(c, c->pool, poolUnits, c->poolLimit <= 0);
     if (rc) return rc;
     StageTimer t(c, SPH_T_PLAN, stream);
     NbArgs A = neighbor_args(c, p, NB_CAP);
-    // persistent single-wave workgroups (each takes its pieces of the pool and of the list)
-    const int planWgs = NB_PLAN_WGS_PER_CU * std::max(1, c->prop.multiProcessorCount);
-    const int grid = std::max(1, std::min((int)tilesBound, planWgs));
+    if (c->poolLimit > 0) A.poolCap = std::min<uint32_t>(A.poolCap, (uint32_t)c->poolLimit);
     k_plan<<<grid, NB_PTHREADS, 0, stream>>>(A);
     HIPCHK(c, hipGetLastError());
     c->havePlan = true;
@@ -1466,7 +1526,8 @@ int sph_step_compat(SphCtx *c, const SphParams *p, const float *pos, const float
     if ((rc = sph_compute_density_and_pressure(c, p))) return rc;
     if ((rc = sph_compute_force(c, p))) return rc;
     if ((rc = read_ecs(c, SPH_BUF_DENSITIES, densities_out))) return rc;
-    return read_ecs(c, SPH_BUF_FORCES, forces_out);
+    if ((rc = read_ecs(c, SPH_BUF_FORCES, forces_out))) return rc;
+    return check_plan_error(c);
 }
 
 // ---- inspection ---------------------------------------------------------------------------
@@ -1518,6 +1579,8 @@ int sph_read(SphCtx *c, int32_t buffer, void *out, size_t bytes)
         return fail(c, SPH_E_INVALID, "slab mode: the ECS-ordered views are not available "
                                       "(sph_slab_download returns the owned particles)");
     HIPCHK(c, hipSetDevice(c->device));
+    if (buffer >= SPH_BUF_DENSITIES && buffer <= SPH_BUF_FORCE_COUNTS) // results of the neighbour kernels
+        if (int rc_ = check_plan_error(c)) return rc_;
     const size_t N = (size_t)c->n;
     const void *src = nullptr;
     size_t need = 0;
@@ -2178,6 +2241,7 @@ int sph_slab_download(SphCtx *c, float *pos_out, float *vel_out, float *density_
     if (!c || !count) return SPH_E_INVALID;
     if (!c->slab) return fail(c, SPH_E_INVALID, "sph_slab_download before sph_slab_upload");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc_ = check_plan_error(c)) return rc_;
     const int n = c->n, cur = c->cur;
     std::vector<float4> hp((size_t)n), hv((size_t)n);
     std::vector<uint32_t> hid((size_t)n);

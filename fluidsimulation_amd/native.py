@@ -33,7 +33,7 @@ EXPORTS = [
     "sph_create", "sph_destroy", "sph_last_error", "sph_device_name", "sph_set_debug",
     "sph_synchronize", "sph_find_grid_size", "sph_set_boundary", "sph_set_colliders",
     "sph_get_colliders", "sph_set_grid", "sph_get_grid", "sph_upload", "sph_download",
-    "sph_seed_volume",
+    "sph_seed_volume", "sph_unpin_host", "sph_pin_stats",
     "sph_hash_position", "sph_radix_sort", "sph_map_table", "sph_reorder",
     "sph_compute_density_and_pressure", "sph_compute_force", "sph_apply_force", "sph_integrate",
     "sph_step_resident", "sph_step", "sph_step_compat", "sph_read", "sph_find_bounds",
@@ -107,6 +107,8 @@ def load():
     lib.sph_get_grid.argtypes = [vp, C.POINTER(SphGrid)]
     lib.sph_upload.argtypes = [vp, vp, vp, vp, vp, i32, f32]
     lib.sph_download.argtypes = [vp, vp, vp]
+    lib.sph_unpin_host.argtypes = [vp, vp]
+    lib.sph_pin_stats.argtypes = [vp, C.POINTER(i32 * 3)]
     lib.sph_seed_volume.argtypes = [vp, vp, vp, vp, f32, vp, f32, f32, i32, C.POINTER(i32)]
     for name in ("sph_hash_position", "sph_compute_density_and_pressure", "sph_compute_force",
                  "sph_apply_force", "sph_integrate"):
@@ -270,6 +272,15 @@ class Context:
         vel = np.empty((self.n, 3), np.float32)
         self._chk(self.lib.sph_download(self.h, _ptr(pos), _ptr(vel)))
         return pos, vel
+
+    def unpin_host(self, array=None):
+        """release the registration of one caller array (None: of all) before it is freed"""
+        self._chk(self.lib.sph_unpin_host(self.h, _ptr(array)))
+
+    def pin_stats(self):
+        st = (C.c_int32 * 3)()
+        self._chk(self.lib.sph_pin_stats(self.h, C.byref(st)))
+        return dict(zip(("registered", "succeeded", "failed"), st))
 
     # -- stages (FluidSPHByGPUSystem.cs:242-247 names)
     def hash_position(self, p):

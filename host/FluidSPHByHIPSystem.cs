@@ -28,7 +28,7 @@ using System;
 [UpdateBefore(typeof(BuildPhysicsWorld))]
 public unsafe partial class FluidSPHByHIPSystem : SystemBase
 {
-    EntityQuery m_Fluid, m_Boundary, m_Boxes;
+    EntityQuery m_Fluid, m_Boundary, m_Boxes, m_Untagged;
     IntPtr m_Ctx = IntPtr.Zero;
     int m_N = -1, m_B = -1, m_BoundaryVersion = -1;
 
@@ -48,6 +48,11 @@ public unsafe partial class FluidSPHByHIPSystem : SystemBase
             All = new ComponentType[] { ComponentType.ReadOnly<PhysicsCollider>(), ComponentType.ReadOnly<Translation>(), ComponentType.ReadOnly<Rotation>() },
             None = new ComponentType[] { typeof(FluidParticleComponent), typeof(BoundaryParticleComponent) },
         });
+        m_Untagged = GetEntityQuery(new EntityQueryDesc
+        {
+            All = FluidSPHUtils.ParticleQueryComponentTypes,
+            None = new ComponentType[] { typeof(PhysicsExclude) },
+        });
         m_BoxList = new NativeList<SphNative.SphBox>(Allocator.Persistent);
         RequireForUpdate(m_Fluid);
         RequireSingletonForUpdate<SimulationSettings>();
@@ -64,10 +69,18 @@ public unsafe partial class FluidSPHByHIPSystem : SystemBase
 
     static void Free<T>(ref NativeArray<T> a) where T : struct { if (a.IsCreated) a.Dispose(); }
 
-    static void Fit<T>(ref NativeArray<T> a, int n) where T : struct
+    // The context is opened with pinHostArrays = 1: the library registers the arrays it is given with
+    // the driver and keeps them registered.  An array must therefore be released from the context
+    // (sph_unpin_host) BEFORE it is disposed: freeing registered memory is undefined, and a new
+    // array at the same address has other pages than the ones still pinned.
+    void Fit<T>(ref NativeArray<T> a, int n) where T : struct
     {
         if (a.IsCreated && a.Length == n) return;
-        if (a.IsCreated) a.Dispose();
+        if (a.IsCreated)
+        {
+            if (m_Ctx != IntPtr.Zero) SphNative.sph_unpin_host(m_Ctx, a.GetUnsafeReadOnlyPtr());
+            a.Dispose();
+        }
         a = new NativeArray<T>(n, Allocator.Persistent, NativeArrayOptions.UninitializedMemory);
     }
 
@@ -189,8 +202,13 @@ public unsafe partial class FluidSPHByHIPSystem : SystemBase
                     v.Linear = outVel[entityInQueryIndex];
                 }).ScheduleParallel(Dependency);
             WriteBackBoxes();
-            // the particles were moved here: keep them out of BuildPhysicsWorld
-            EntityManager.AddComponent<PhysicsExclude>(m_Fluid);
+            // the particles were moved here: keep them out of BuildPhysicsWorld.  A structural
+            // change, so only when some particle still lacks the tag (new particles), not per frame.
+            if (m_Untagged.CalculateEntityCount() > 0)
+            {
+                Dependency.Complete();
+                EntityManager.AddComponent<PhysicsExclude>(m_Untagged);
+            }
         }
         gridSize.Dispose(Dependency);
     }

@@ -122,6 +122,8 @@ public static unsafe class SphNative
     [DllImport(Lib)] public static extern int sph_get_grid(IntPtr ctx, SphGrid* gridOut);
     [DllImport(Lib)] public static extern int sph_upload(IntPtr ctx, void* pos, void* vel, void* invMass, void* particles, int N, float gridSize);
     [DllImport(Lib)] public static extern int sph_download(IntPtr ctx, void* posOut, void* velOut);
+    [DllImport(Lib)] public static extern int sph_unpin_host(IntPtr ctx, void* array);
+    [DllImport(Lib)] public static extern int sph_pin_stats(IntPtr ctx, int* stats3);
     [DllImport(Lib)] public static extern int sph_seed_volume(IntPtr ctx, float* localToWorld, float* boundsMin, float* boundsSize, float radius, SphParticle* particle, float invMass, float gridSize, int append, int* added);
 
     // ---- stages (one per dispatch of FluidSPHByGPUSystem.cs:242-247, then the CPU-side jobs)

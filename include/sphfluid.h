@@ -95,8 +95,9 @@ typedef struct SphConfig {
                                 neighbour kernels only */
     int32_t pinHostArrays;   /* !=0: caller arrays of sph_upload / sph_download / sph_step* are
                                 registered with the driver on first use (hipHostRegister) and stay
-                                registered until sph_destroy: use it when the same arrays come
-                                back every frame and outlive the context (persistent NativeArrays) */
+                                registered until sph_unpin_host / sph_destroy: use it when the same
+                                arrays come back every frame (persistent NativeArrays), and call
+                                sph_unpin_host before freeing one */
 } SphConfig;
 
 /* Periodic cell table the dense sort key is built on (DESIGN.md "cell keys").  A particle in
@@ -188,6 +189,14 @@ SPH_API int sph_upload(SphCtx *ctx, const float *pos /* N*3 */, const float *vel
                        const float *invMass /* N */, const SphParticle *params /* N */,
                        int32_t N, float gridSize);
 SPH_API int sph_download(SphCtx *ctx, float *pos_out /* N*3 */, float *vel_out /* N*3 */);
+/* SphConfig.pinHostArrays bookkeeping (the reference's ComputeBuffer.SetData / AsyncGPUReadback
+ * span, FluidSPHByGPUSystem.cs:227-233,249-252, stages through driver-owned memory; here the
+ * caller's arrays themselves are registered).  sph_unpin_host releases the registration of one
+ * array (array == NULL: of all): call it BEFORE freeing or reallocating an array the context has
+ * seen.  sph_pin_stats: stats[0] = arrays registered now, [1] = registrations that succeeded,
+ * [2] = that failed (those arrays are copied from pageable memory), since sph_create. */
+SPH_API int sph_unpin_host(SphCtx *ctx, const void *array);
+SPH_API int sph_pin_stats(SphCtx *ctx, int32_t stats[3]);
 /* FluidInitializeSystem.CreateParticles (FluidInitializeSystem.cs:63-92) on the device, so that a
  * scene never crosses PCIe: fills the local box [boundsMin, boundsMin +
  * boundsSize] of an authoring volume with a lattice at spacing 2*radius in world units, x fastest
