@@ -1239,3 +1239,85 @@ void k_neighbors(NbArgs A)
         i = sh.next;
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// PARITY AUDIT of the production neighbour set (tests only; no reference counterpart).
+// The production density pass decides with the sign of fma(d2, -1/h2, 1) which candidates the
+// force pass will see, and leaves that decision as hit-mask words behind every block's plan.
+// This kernel walks plan and masks the way the force pass does and gives, per target (sorted
+// order), the number of hits and the sum of the hits' ids -- fluid: ECS id, boundary: bndBase +
+// index in the caller's boundary array -- so that a test can compare the SET with the reference's
+// predicate d2 < h2 (FluidSPHByCPUSystem.cs:97).  One wave per block.  invalid counts bits that
+// point outside the block's image (there must be none).
+__global__ __launch_bounds__(64) void k_audit_masks(NbArgs A, const uint32_t *__restrict__ oid,
+                                                    const uint32_t *__restrict__ bperm, uint32_t bndBase,
+                                                    int *__restrict__ counts,
+                                                    unsigned long long *__restrict__ idsum,
+                                                    uint32_t *__restrict__ invalid)
+{
+    const int lane = threadIdx.x;
+    const uint32_t nblocks = min(A.ctl[NB_CTL_BLOCKS], (uint32_t)A.blockCap);
+    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const BlockHdr hdr = A.blockList[b];
+        if (hdr.w == 0) continue;
+        const int nh = hdr.z & 0xff, nunits = (hdr.z >> 8) & 0xff;
+        const int total = hdr.w & 0x7ff, nslots = (hdr.w >> 20) & 0xfff;
+        const int4 *hinfo = (const int4 *)(A.pool + hdr.x);
+        const UnitDesc *units = (const UnitDesc *)(hinfo + nh);
+        const uint32_t *slotTab = (const uint32_t *)(units + nunits);
+        const int planBytes = nh * 16 + nunits * 32 + nslots * 4;
+        const uint32_t *maskBlk = (const uint32_t *)(A.pool + hdr.x + (planBytes >> 4));
+        for (int unit = 0; unit < nunits; unit++) {
+            const UnitDesc ud = units[unit];
+            const int T = ud.tS & 0xff, S = ud.tS >> 8, nA = ud.nAB & 0xffff, nB = ud.nAB >> 16;
+            int u, s;
+            split_lane(lane, S, u, s);
+            if (u >= T) continue;
+            int cnt = 0;
+            unsigned long long sum = 0;
+            const int nwords = (nA + nB + 31) >> 5;
+            for (int j = 0; j < nwords; j++) {
+                uint32_t m = __builtin_bitreverse32(maskBlk[(size_t)(ud.maskw + j) * 64 + lane]);
+                while (m) {
+                    const int k = 32 * j + __builtin_ctz(m);
+                    m &= m - 1;
+                    int rec = -1;
+                    if (k < nA + nB) {
+                        const uint32_t e = slotTab[ud.slotA + k];
+                        if (k < nA || s < (int)(e >> 16)) rec = (int)((e & 0xffffu) >> 4) + s;
+                    }
+                    if (rec < 0 || rec >= total) {
+                        atomicAdd(invalid, 1u);
+                        continue;
+                    }
+                    int lo = 0, hi = nh - 1; // the last halo cell that starts at or before rec
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (hinfo[mid].x <= rec) lo = mid;
+                        else hi = mid - 1;
+                    }
+                    const int4 hi4 = hinfo[lo];
+                    const int k2 = rec - hi4.x, fc = hi4.z & 0xffff, bc = hi4.z >> 16;
+                    if (k2 < fc) sum += oid[hi4.y + k2] & 0x3fffffffu;
+                    else if (k2 < fc + bc) sum += (unsigned long long)bndBase + bperm[hi4.w + (k2 - fc)];
+                    else atomicAdd(invalid, 1u);
+                    cnt++;
+                }
+            }
+            atomicAdd(&counts[ud.gi0 + u], cnt);
+            atomicAdd(&idsum[ud.gi0 + u], sum);
+        }
+    }
+}
+
+// targets of the cells that took the global-memory path carry no masks: count -1
+__global__ void k_audit_gcells(NbArgs A, int *__restrict__ counts)
+{
+    const uint32_t ncells = min(A.ctl[NB_CTL_GCELLS], (uint32_t)A.gcellCap);
+    for (uint32_t i = blockIdx.x; i < ncells; i += gridDim.x) {
+        const int2 gc = A.gcellList[i];
+        const int lx = gc.y & 0xff, ly = (gc.y >> 8) & 0xff, lz = (gc.y >> 16) & 0xff;
+        const int2 r = A.table[(uint32_t)gc.x * SPH_TCELLS + (uint32_t)((lz * SPH_TY + ly) * SPH_TX + lx)];
+        for (int t = r.x + (int)threadIdx.x; t < r.y; t += blockDim.x) counts[t] = -1;
+    }
+}

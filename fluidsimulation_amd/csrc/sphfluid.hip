@@ -1571,6 +1571,54 @@ static int read_ecs(SphCtx *c, int32_t buffer, void *out)
     return SPH_OK;
 }
 
+// SPH_BUF_MASK_COUNTS / SPH_BUF_MASK_IDSUMS: the production density pass's hit masks, walked as the
+// force pass walks them (k_audit_masks), per particle in ECS order
+static int read_mask_audit(SphCtx *c, int32_t buffer, void *out, size_t bytes)
+{
+    const int N = c->n, cur = c->cur;
+    if (!c->havePlan || !c->haveMasks || !c->ordered)
+        return fail(c, SPH_E_INVALID, "no hit masks: run the production density pass (no SPH_DEBUG_COUNTS) first");
+    const size_t need = (buffer == SPH_BUF_MASK_COUNTS ? 4 : 8) * (size_t)N;
+    if (bytes != need) return fail(c, SPH_E_INVALID, "size mismatch: need %zu bytes", need);
+    DevBuf<int> cnt;
+    DevBuf<unsigned long long> sum, sumEcs;
+    DevBuf<uint32_t> inv;
+    int rc = ensure(c, cnt, (size_t)N, false);
+    if (!rc) rc = ensure(c, sum, (size_t)N, false);
+    if (!rc) rc = ensure(c, sumEcs, (size_t)N, false);
+    if (!rc) rc = ensure(c, inv, 1, false);
+    if (!rc) rc = ensure(c, c->io1, (size_t)N);
+    uint32_t invalid = 0;
+    if (!rc) {
+        SphParams dummy{};
+        NbArgs A = neighbor_args(c, &dummy, NB_CAP);
+        hipError_t e = hipMemsetAsync(cnt.p, 0, (size_t)4 * N, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(sum.p, 0, (size_t)8 * N, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(inv.p, 0, 4, c->stream);
+        if (e == hipSuccess) {
+            k_audit_masks<<<2048, 64, 0, c->stream>>>(A, c->oid[cur].p, c->nb > 0 ? c->bperm : nullptr,
+                                                      (uint32_t)N, cnt.p, sum.p, inv.p);
+            k_audit_gcells<<<256, 64, 0, c->stream>>>(A, cnt.p);
+            const int nb = blocks_for(N, 256);
+            if (buffer == SPH_BUF_MASK_COUNTS) {
+                k_unpack1<int><<<nb, 256, 0, c->stream>>>(cnt.p, c->oid[cur].p, N, (int *)c->io1.p);
+                e = hipMemcpyAsync(out, c->io1.p, need, hipMemcpyDeviceToHost, c->stream);
+            } else {
+                k_unpack1<unsigned long long><<<nb, 256, 0, c->stream>>>(sum.p, c->oid[cur].p, N, sumEcs.p);
+                e = hipMemcpyAsync(out, sumEcs.p, need, hipMemcpyDeviceToHost, c->stream);
+            }
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&invalid, inv.p, 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(c, SPH_E_DEVICE, "mask audit: %s", hipGetErrorString(e));
+    }
+    release(cnt); release(sum); release(sumEcs); release(inv);
+    if (!rc && invalid)
+        rc = fail(c, SPH_E_DEVICE, "mask audit: %u hit bits point outside their block's image", invalid);
+    return rc;
+}
+
 int sph_read(SphCtx *c, int32_t buffer, void *out, size_t bytes)
 {
     if (!c || !out) return SPH_E_INVALID;
@@ -1613,6 +1661,9 @@ int sph_read(SphCtx *c, int32_t buffer, void *out, size_t bytes)
     case SPH_BUF_POSITIONS: case SPH_BUF_VELOCITIES:
         if (bytes != 12 * N) return fail(c, SPH_E_INVALID, "size mismatch: need %zu bytes", 12 * N);
         return read_ecs(c, buffer, out);
+    case SPH_BUF_MASK_COUNTS: case SPH_BUF_MASK_IDSUMS:
+        if (int rc_ = check_plan_error(c)) return rc_;
+        return read_mask_audit(c, buffer, out, bytes);
     default: return fail(c, SPH_E_INVALID, "unknown buffer %d", buffer);
     }
     if (!ok || !src) return fail(c, SPH_E_INVALID, "buffer %d is not available at this point", buffer);

@@ -23,7 +23,7 @@ STAGE_NAMES = ["keys", "sort", "table", "reorder", "density", "force", "integrat
 (SPH_BUF_HASHES, SPH_BUF_CELLS, SPH_BUF_KEYS, SPH_BUF_PERM, SPH_BUF_SORTED_KEYS, SPH_BUF_TABLE,
  SPH_BUF_DENSITIES, SPH_BUF_PRESSURES, SPH_BUF_FORCES, SPH_BUF_DENSITY_COUNTS,
  SPH_BUF_FORCE_COUNTS, SPH_BUF_POSITIONS, SPH_BUF_VELOCITIES, SPH_BUF_BOUNDARY_PERM,
- SPH_BUF_BOUNDARY_TABLE) = range(15)
+ SPH_BUF_BOUNDARY_TABLE, SPH_BUF_MASK_COUNTS, SPH_BUF_MASK_IDSUMS) = range(17)
 
 SPH_DEBUG_HASHES, SPH_DEBUG_COUNTS, SPH_DEBUG_NO_LDS_TILE = 1, 2, 4
 SPH_SORT_NOALLOC_MAX = 1 << 20
@@ -362,8 +362,10 @@ class Context:
             out = np.empty((self.get_grid()[3], 2), np.int32)
         elif buffer in (SPH_BUF_DENSITIES, SPH_BUF_PRESSURES):
             out = np.empty(n, np.float32)
-        elif buffer in (SPH_BUF_DENSITY_COUNTS, SPH_BUF_FORCE_COUNTS):
+        elif buffer in (SPH_BUF_DENSITY_COUNTS, SPH_BUF_FORCE_COUNTS, SPH_BUF_MASK_COUNTS):
             out = np.empty(n, np.int32)
+        elif buffer == SPH_BUF_MASK_IDSUMS:
+            out = np.empty(n, np.uint64)
         elif buffer in (SPH_BUF_FORCES, SPH_BUF_POSITIONS, SPH_BUF_VELOCITIES):
             out = np.empty((n, 3), np.float32)
         else:

@@ -23,7 +23,8 @@ public static unsafe class SphNative
     public enum Buf
     {
         Hashes = 0, Cells, Keys, Perm, SortedKeys, Table, Densities, Pressures, Forces,
-        DensityCounts, ForceCounts, Positions, Velocities, BoundaryPerm, BoundaryTable
+        DensityCounts, ForceCounts, Positions, Velocities, BoundaryPerm, BoundaryTable,
+        MaskCounts, MaskIdSums
     }
 
     // FluidParticleComponent (FluidParticleComponent.cs:9-12) has this layout: a

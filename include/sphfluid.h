@@ -140,7 +140,16 @@ enum {
     SPH_BUF_POSITIONS,       /* f32[N*3] ECS order                                              */
     SPH_BUF_VELOCITIES,      /* f32[N*3] ECS order                                              */
     SPH_BUF_BOUNDARY_PERM,   /* u32[B]                                                          */
-    SPH_BUF_BOUNDARY_TABLE   /* i32[cells*2]                                                    */
+    SPH_BUF_BOUNDARY_TABLE,  /* i32[cells*2]                                                    */
+    /* Parity audit of the PRODUCTION neighbour set: the hit masks the production density pass
+     * leaves for the force pass (candidates with fma(d2, -1/h2, 1) >= 0), walked as the force
+     * pass walks them.  Per particle, ECS order: number of hits (self and boundary included, the
+     * counterpart of SPH_BUF_DENSITY_COUNTS; -1 for a particle of a cell that took the
+     * global-memory path, which has no masks) and the sum of the hits' ids, fluid ids as given to
+     * sph_upload, boundary particle k as N + k.  Needs the production density pass (no
+     * SPH_DEBUG_COUNTS) on the current ordering. */
+    SPH_BUF_MASK_COUNTS,     /* i32[N]                                                          */
+    SPH_BUF_MASK_IDSUMS      /* u64[N]                                                          */
 };
 
 typedef struct SphCtx SphCtx;

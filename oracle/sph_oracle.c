@@ -527,7 +527,14 @@ static inline void cross3(const float *a, const float *b, float *o)
 }
 
 /* particles: x += v*dt, then sphere(radius params[4i]) vs every box in order.
+ * Swept: a particle that moves farther than its radius in the step takes the step in
+ * m = ceil(|v| dt / r) equal pieces (at most ORC_MAX_SUBSTEPS) and is tested against the boxes
+ * after each, so that its centre is never carried through a face: a piece no longer than r cannot
+ * take a centre that is at least r outside a box to the inside of it.  The position of piece s is
+ * xb + v (t_s - tb), (xb, tb) = where and when the particle last touched a box (the start of the
+ * step at first): without a contact the end position is x + v dt exactly as without pieces.
  * body_impulse: K x 6 floats (linear impulse, angular impulse about the centre), accumulated. */
+#define ORC_MAX_SUBSTEPS 64
 ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMass,
                                      const float *params, int n, const OrcBox *boxes, int nboxes,
                                      float dt, float particleRestitution, float *body_impulse)
@@ -536,12 +543,22 @@ ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMas
     for (int k = 0; k < nboxes; k++) quat_to_mat(boxes[k].rot, mats + 9 * k);
     if (body_impulse) memset(body_impulse, 0, sizeof(float) * 6 * (size_t)nboxes);
     for (int i = 0; i < n; i++) {
-        float x[3], v[3];
+        float x[3], v[3], xb[3], tb = 0.0f;
         float r = params[4 * i];
         for (int a = 0; a < 3; a++) {
             v[a] = vel[3 * i + a];
-            x[a] = pos[3 * i + a] + v[a] * dt;
+            xb[a] = x[a] = pos[3 * i + a];
         }
+        int msub = 1;
+        if (nboxes > 0) {
+            float sp = sqrtf(dot3(v, v)) * dt;
+            if (sp > r) msub = (int)fminf(ceilf(sp / r), (float)ORC_MAX_SUBSTEPS);
+        }
+        for (int s = 1; s <= msub; s++) {
+        const float ts = s == msub ? dt : dt * ((float)s / (float)msub);
+        const float tau = ts - tb;
+        int touched = 0;
+        for (int a = 0; a < 3; a++) x[a] = xb[a] + v[a] * tau;
         for (int k = 0; k < nboxes; k++) {
             const OrcBox *bx = &boxes[k];
             const float *m = mats + 9 * k;
@@ -568,6 +585,7 @@ ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMas
                 nl[best] = p[best] < 0.0f ? -1.0f : 1.0f;
                 pen = bestd + r;
             }
+            touched = 1;
             float nw[3];
             mat_mul(m, nl, nw);
             for (int a = 0; a < 3; a++) x[a] = x[a] + nw[a] * pen;
@@ -584,8 +602,8 @@ ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMas
                 int dynamic = bx->invMass != 0.0f || bx->invInertia[0] != 0.0f ||
                               bx->invInertia[1] != 0.0f || bx->invInertia[2] != 0.0f;
                 if (!dynamic) {
-                    float s = (1.0f + e) * vn;
-                    for (int a = 0; a < 3; a++) v[a] = v[a] - s * nw[a];
+                    float sc = (1.0f + e) * vn;
+                    for (int a = 0; a < 3; a++) v[a] = v[a] - sc * nw[a];
                 } else {
                     float rxn[3], loc[3], w[3];
                     cross3(rc, nw, rxn);
@@ -603,6 +621,11 @@ ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMas
                         }
                 }
             }
+        }
+        if (touched) {
+            for (int a = 0; a < 3; a++) xb[a] = x[a];
+            tb = ts;
+        }
         }
         for (int a = 0; a < 3; a++) {
             pos[3 * i + a] = x[a];

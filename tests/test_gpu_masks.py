@@ -1,0 +1,119 @@
+"""Audit of the PRODUCTION neighbour set.
+
+The exact-predicate kernels (SPH_DEBUG_COUNTS) give bit-exact neighbour counts, but they are not
+what runs in production: there the density pass decides with the sign of fma(d2, -1/h2, 1), d2
+fma-contracted, which candidates the force pass will see.  These tests read that decision back
+(SPH_BUF_MASK_COUNTS / SPH_BUF_MASK_IDSUMS: per particle the number of hits and the sum of their
+ids) and compare the SET with the reference's predicate d2 < h2 evaluated in its own arithmetic,
+(dx*dx + dy*dy) + dz*dz in fp32 without contraction (FluidSPHByCPUSystem.cs:97): every pair on which
+the two disagree must lie within BAND_ULP ulp of the support radius, where its density weight
+(h2 - d2)^3 is ~1e-20 of a neighbour's and its force terms ~(h - r)^2 are zero to fp32.
+"""
+import itertools
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+from fluidsimulation_amd import native, scene
+from tests.util import load_scene, run_to_force
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+BAND_ULP = 4  # |d2 - h2| <= BAND_ULP * ulp(h2): the only pairs the two predicates may disagree on
+
+
+def reference_pairs(sc):
+    """all (i, j, d2) with j a fluid (j < N) or boundary (j >= N) particle near i, d2 in the
+    reference's fp32 arithmetic; and h2 per i"""
+    n = len(sc.pos)
+    allp = np.concatenate([sc.pos, sc.bpos]).astype(np.float32)
+    h = (sc.params[:, 0] * np.float32(4.0)).astype(np.float32)
+    h2 = (h * h).astype(np.float32)
+    tree_all = cKDTree(allp.astype(np.float64))
+    tree_f = cKDTree(sc.pos.astype(np.float64))
+    sp = tree_f.sparse_distance_matrix(tree_all, float(h.max()) * (1.0 + 1e-4), output_type="ndarray")
+    i, j = sp["i"].astype(np.int64), sp["j"].astype(np.int64)
+    # cKDTree drops pairs at distance exactly 0 from a sparse matrix only if asked to; make sure
+    # every particle has itself
+    self_missing = np.setdiff1d(np.arange(n), i[i == j])
+    i = np.concatenate([i, self_missing])
+    j = np.concatenate([j, self_missing])
+    d = allp[i] - allp[j]                       # fp32
+    d2 = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).astype(np.float32)
+    return i, j, d2, h2
+
+
+def audit(ctx, sc, oracle_counts=None):
+    n = len(sc.pos)
+    p = load_scene(ctx, sc, debug=0)
+    run_to_force(ctx, p)
+    cnt = ctx.read(native.SPH_BUF_MASK_COUNTS).astype(np.int64)
+    ids = ctx.read(native.SPH_BUF_MASK_IDSUMS)
+    assert (cnt >= 0).all(), "a cell took the global-memory path: no masks to audit"
+    i, j, d2, h2 = reference_pairs(sc)
+    hit = d2 < h2[i]
+    ref_cnt = np.bincount(i[hit], minlength=n)
+    ref_ids = np.bincount(i[hit], weights=j[hit].astype(np.float64), minlength=n).astype(np.uint64)
+    if oracle_counts is not None:  # the numpy restatement agrees with the oracle / golden counts
+        np.testing.assert_array_equal(ref_cnt, oracle_counts)
+    ulp = np.spacing(h2[i])
+    band = np.abs(d2.astype(np.float64) - h2[i]) <= BAND_ULP * ulp
+    differ = np.nonzero((cnt != ref_cnt) | (ids != ref_ids))[0]
+    npairs = 0
+    for t in differ:
+        sel = np.nonzero((i == t) & band)[0]
+        want = (int(cnt[t]) - int(ref_cnt[t]), int(ids[t]) - int(ref_ids[t]))
+        # a band pair that the reference counts may be missing from the masks, one it does not
+        # count may be in them: some subset of those flips must explain the difference
+        flips = [(-1, -int(j[k])) if hit[k] else (1, int(j[k])) for k in sel]
+        ok = False
+        for r in range(1, len(flips) + 1):
+            for combo in itertools.combinations(flips, r):
+                if (sum(c[0] for c in combo), sum(c[1] for c in combo)) == want:
+                    ok, npairs = True, npairs + r
+                    break
+            if ok:
+                break
+        assert ok, (f"particle {t}: production hit set differs from d2 < h2 by (count, id sum) "
+                    f"{want}, not explained by its {len(sel)} pairs within {BAND_ULP} ulp of h2")
+    return len(differ), npairs, int(band.sum()), int(hit.sum())
+
+
+@pytest.mark.parametrize("name", ["demo_step0", "jitter_32k"])
+def test_production_hit_masks_equal_reference_sets(ctx, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    if name == "demo_step0":
+        sc = scene.demo_scene()
+    else:
+        sc = scene.dam_break(32, 32, 32, jitter_seed=0x5EED0003)
+        sc.vel = np.load(os.path.join(GOLD, "jitter_32k_vel.npy")).astype(np.float32)
+    ntargets, npairs, nband, nhits = audit(ctx, sc, oracle_counts=g["dcnt"])
+    print(f"{name}: {nhits} reference pairs, {nband} within {BAND_ULP} ulp of h2, "
+          f"{npairs} decided differently by the production kernel ({ntargets} particles)")
+    if name == "jitter_32k":
+        # jittered positions: no pair sits on the support radius, the sets are identical
+        assert npairs == 0
+
+
+def test_production_hit_masks_on_knife_edge_pairs(ctx):
+    """pairs placed within a few ulp of h on purpose (the scene of test_knife_edge_predicates):
+    the production sets may differ from the reference's on those pairs and on no others"""
+    rng = np.random.default_rng(42)
+    n = 4096
+    base = rng.uniform(2.0, 30.0, (n // 2, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n // 2, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    eps = rng.integers(-6, 7, n // 2) * 6e-8
+    other = (base.astype(np.float64) + dirs * (1.0 + eps)[:, None]).astype(np.float32)
+    sc = scene.dam_break(2, 2, 2)
+    sc.pos = np.concatenate([base, other]).astype(np.float32)
+    sc.vel = np.zeros_like(sc.pos)
+    sc.params = np.tile(sc.params[:1], (n, 1))
+    sc.inv_mass = np.tile(sc.inv_mass[:1], n)
+    sc.bpos, sc.bparams = sc.bpos[:0], sc.bparams[:0]
+    ntargets, npairs, nband, nhits = audit(ctx, sc)
+    print(f"knife edge: {nhits} reference pairs, {nband} within {BAND_ULP} ulp of h2, "
+          f"{npairs} decided differently ({ntargets} particles)")
+    assert nband > 200  # the scene does put pairs on the edge
