@@ -9,7 +9,8 @@
 // (sph_device.h).  A tile is worked through in BLOCKS: the whole tile when its halo (block + one
 // cell on every side) fits the LDS image, else parts (4x2x2, 4x2x1, 2x2x1), else single cells
 // (the fluid compresses several-fold at the bottom of a deep tank), else -- for a cell whose
-// 27-cell neighbourhood still overflows -- a walk straight from global memory.
+// 27-cell neighbourhood still overflows -- the cell's targets against chunks of candidates streamed
+// through the image (process_cell_chunked).
 //
 // Plan once, execute twice.  All the integer bookkeeping of a block is the same for the density
 // and the force pass, and it is latency-bound work (table look-ups, scans, dependent LDS reads)
@@ -527,73 +528,6 @@ template <bool FORCE> __device__ __forceinline__ float4 finish_constants(const f
 __device__ __forceinline__ int div_small(int a, int b)
 {
     return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b));
-}
-
-// one cell straight from global memory (its 27-cell neighbourhood overflows the LDS tile)
-template <bool FORCE, bool COUNT>
-__device__ void process_cell_global(const HaloTab &sh, const NbArgs &A, int lx, int ly, int lz)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int f = tile_halo_index(lx + 1, ly + 1, lz + 1);
-    const int ncell = uniform_i(sh.fc[f]);
-    const int cstart = uniform_i(sh.fs[f]);
-    constexpr int NB_WAVES = (FORCE ? NB_FTHREADS : NB_DTHREADS) / 64;
-    const int per = (ncell + NB_WAVES - 1) / NB_WAVES; // the waves share the targets
-    const int t0 = w * per, t1 = min(ncell, t0 + per);
-    for (int tb = t0; tb < t1; tb += 64) {
-        const int T = min(64, t1 - tb);
-        const int S = slices_for(T);
-        int u, slice;
-        split_lane(lane, S, u, slice);
-        const bool active = u < T;
-        const int ti = cstart + tb + (active ? u : 0);
-        Pass<FORCE, COUNT> ps;
-        float tkv, thr;
-        const uint32_t mi = A.mat[ti];
-        loop_constants<FORCE>(A.mats[mi], tkv, thr);
-        const float4 fc4 = finish_constants<FORCE>(finish_row<FORCE, COUNT>(A.mats + mi), FORCE ? A.rhoIn[ti] : 0.f);
-        const float4 tp = A.posm[ti];
-        ps.t.x = tp.x; ps.t.y = tp.y; ps.t.z = tp.z;
-        if constexpr (FORCE) {
-            const float4 tv = A.velq[ti];
-            ps.t.vx = tv.x; ps.t.vy = tv.y; ps.t.vz = tv.z;
-            ps.t.Pi = tv.w;
-            ps.t.negInvH = tkv;
-            ps.t.tiny = 1.0e-30f;
-            ps.t.thrF = thr;
-        } else {
-            ps.t.negInvH2 = tkv;
-            ps.t.h2 = thr;
-        }
-        for (int c27 = 0; c27 < 27; c27++) {
-            const int h = f + ((c27 / 9) - 1) * (NB_HX * NB_HY) + (((c27 / 3) % 3) - 1) * NB_HX +
-                          (c27 % 3) - 1;
-            { // fluid neighbours (index != j, :152)
-                const int s0 = uniform_i(sh.fs[h]), e0 = s0 + uniform_i(sh.fc[h]);
-                for (int k0 = s0; k0 < e0; k0 += S) {
-                    const int k = k0 + slice;
-                    float4 cp = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f);
-                    float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k < e0) {
-                        cp = A.posm[k];
-                        if (FORCE) cv = A.velq[k];
-                    }
-                    ps.pair(cp, cv, k != ti);
-                }
-            }
-            { // boundary neighbours: rho_j = rho0_j, p_j = 0, v_j = 0 (:184-189)
-                const int s0 = uniform_i(sh.bs[h]), e0 = s0 + uniform_i(sh.bc[h]);
-                for (int k0 = s0; k0 < e0; k0 += S) {
-                    const int k = k0 + slice;
-                    float4 cp = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f);
-                    if (k < e0) cp = A.bposm[k];
-                    ps.pair(cp, make_float4(0.f, 0.f, 0.f, 0.f), true);
-                }
-            }
-        }
-        const float4 F = ps.finish(A, S, slice, active && slice == 0, ti, fc4);
-        if (FORCE && active && slice == 0) A.force[ti] = F;
-    }
 }
 
 
@@ -1183,6 +1117,95 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
     NB_STAMP((FORCE ? 16 : 8) + 4);
 }
 
+// A cell whose 27-cell neighbourhood overflows the LDS image (the bottom of a deep tank while the
+// column lands: hundreds of particles per cell).  The reference's hash chains have no occupancy
+// limit (FluidSPHByCPUSystem.cs:69-75); here the cell's targets stay in registers -- 32 per wave,
+// two candidate slices each -- and the candidates of its 27 cells, fluid then boundary per cell,
+// are streamed through the same image in chunks by LDS-DMA, every wave walking each chunk for its
+// own targets.  (Round 2 read every candidate from global memory per lane: 14-19 ms per step on
+// C3 while the column lands.)  No hit masks: the force pass walks every candidate here too.
+template <bool FORCE, bool COUNT>
+__device__ void process_cell_chunked(NbShared<FORCE, COUNT> &sh, const HaloTab &ht, const NbArgs &A,
+                                     int lx, int ly, int lz)
+{
+    constexpr int NT = FORCE ? NB_FTHREADS : NB_DTHREADS, NB_WAVES = NT / 64;
+    constexpr int TPW = 32;            // targets per wave and pass
+    constexpr int CHUNK = NB_CAP - 64; // candidate records per chunk; 64 FAR records follow them
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int f = tile_halo_index(lx + 1, ly + 1, lz + 1);
+    const int ncell = uniform_i(ht.fc[f]), cstart = uniform_i(ht.fs[f]);
+    float4 *recP = sh.recP, *recV = sh.recV;
+    for (int tb = 0; tb < ncell; tb += NB_WAVES * TPW) { // (workgroup-uniform)
+        const int t0 = tb + w * TPW;
+        const int T = max(0, min(TPW, ncell - t0)); // wave-uniform; 0: the wave only helps to copy
+        const int S = T > 0 ? slices_for(T) : 64;
+        int u, slice;
+        split_lane(lane, S, u, slice);
+        const bool active = T > 0 && u < T;
+        const int ti = cstart + (T > 0 ? t0 : 0) + (active ? u : 0);
+        Pass<FORCE, COUNT> ps;
+        float tkv, thr;
+        const uint32_t mi = A.mat[ti];
+        loop_constants<FORCE>(A.mats[mi], tkv, thr);
+        const float4 fc4 = finish_constants<FORCE>(finish_row<FORCE, COUNT>(A.mats + mi), FORCE ? A.rhoIn[ti] : 0.f);
+        const float4 tp = A.posm[ti];
+        ps.t.x = tp.x; ps.t.y = tp.y; ps.t.z = tp.z;
+        if constexpr (FORCE) {
+            const float4 tv = A.velq[ti];
+            ps.t.vx = tv.x; ps.t.vy = tv.y; ps.t.vz = tv.z;
+            ps.t.Pi = tv.w;
+            ps.t.negInvH = tkv;
+            ps.t.tiny = 1.0e-30f;
+            ps.t.thrF = thr;
+        } else {
+            ps.t.negInvH2 = tkv;
+            ps.t.h2 = thr;
+        }
+        for (int c27 = 0; c27 < 27; c27++) {
+            const int h = f + ((c27 / 9) - 1) * (NB_HX * NB_HY) + (((c27 / 3) % 3) - 1) * NB_HX +
+                          (c27 % 3) - 1;
+            for (int kind = 0; kind < 2; kind++) { // fluid (index != j, :152), then boundary (:184-189)
+                const bool fluid = kind == 0;
+                const int s0 = uniform_i(fluid ? ht.fs[h] : ht.bs[h]);
+                const int e0 = s0 + uniform_i(fluid ? ht.fc[h] : ht.bc[h]);
+                const float4 *srcP = fluid ? A.posm : A.bposm;
+                for (int c0 = s0; c0 < e0; c0 += CHUNK) {
+                    const int cnt = min(CHUNK, e0 - c0);
+                    lds_barrier(); // every wave is done with the chunk before
+                    for (int p0 = w * 64; p0 < cnt + 64; p0 += NT) { // wave-uniform
+                        const int k = p0 + lane;
+                        if (k < cnt) {
+                            __builtin_amdgcn_global_load_lds((gptr_t)(srcP + c0 + k), (lptr_t)(recP + p0), 16, 0, 0);
+                            if (FORCE) {
+                                const float4 *gv = fluid ? (const float4 *)A.velq + c0 + k : A.zeros;
+                                __builtin_amdgcn_global_load_lds((gptr_t)gv, (lptr_t)(recV + p0), 16, 0, 0);
+                            }
+                        } else if (k < cnt + 64) { // what the last slot's slices past the end read
+                            recP[k] = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f);
+                            if (FORCE) recV[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+                    __syncthreads(); // (waits for the DMA)
+                    if (T > 0) {
+                        const int self = fluid ? ti - c0 : -1; // the target's own place in the chunk
+                        for (int k0 = 0; k0 < cnt; k0 += S) {
+                            const int k = k0 + slice;
+                            const float4 cp = recP[k];
+                            float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (FORCE) cv = recV[k];
+                            keep_b128(cp);
+                            if (FORCE) keep_b128x(cv);
+                            ps.pair(cp, cv, k != self);
+                        }
+                    }
+                }
+            }
+        }
+        const float4 F = ps.finish(A, S, slice, active && slice == 0, ti, fc4);
+        if (FORCE && active && slice == 0) A.force[ti] = F;
+    }
+}
+
 // Persistent workgroups.  Blocks are taken from the list in chunks of NB_CHUNK: workgroup b starts
 // with chunk b, the chunks behind the first gridDim.x come from one device-wide counter (a single
 // word serves about 88 returning atomics per microsecond on this chip, so one atomic per block
@@ -1232,7 +1255,7 @@ void k_neighbors(NbArgs A)
     for (uint32_t i = blockIdx.x; i < ncells;) {
         const int2 gc = A.gcellList[i];
         tile_lookup(ht, gc.x, A);
-        process_cell_global<FORCE, COUNT>(ht, A, gc.y & 0xff, (gc.y >> 8) & 0xff, (gc.y >> 16) & 0xff);
+        process_cell_chunked<FORCE, COUNT>(sh, ht, A, gc.y & 0xff, (gc.y >> 8) & 0xff, (gc.y >> 16) & 0xff);
         __syncthreads();
         if (tid == 0) sh.next = atomicAdd(&A.ctl[A.queue + 1], 1u) + gridDim.x;
         __syncthreads();

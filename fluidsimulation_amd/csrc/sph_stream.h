@@ -152,15 +152,25 @@ __global__ __launch_bounds__(256) void k_reorder(
     __shared__ uint32_t ids[256];
     const int blockBase = blockIdx.x * 256;
     const int s = blockBase + threadIdx.x;
-    uint32_t c = 0, id = 0;
+    uint32_t c = 0, id = 0, key = 0;
     if (s < n) {
         c = perm[s];
+        key = skeys[s];
         id = oidIn[c];
+    }
+    // the record itself is fetched now and travels in registers while the rank is worked out (four
+    // gathers in flight instead of one dependent load after the other)
+    float4 pm = make_float4(0.f, 0.f, 0.f, 0.f), vq = pm;
+    uint32_t mt = 0;
+    if (s < n) {
+        pm = posmIn[c];
+        vq = velqIn[c];
+        mt = matIn[c];
     }
     ids[threadIdx.x] = id;
     __syncthreads();
     if (s >= n) return;
-    const int2 cell = table[skeys[s]];
+    const int2 cell = table[key];
     int rank = 0;
     for (int t = cell.x; t < cell.y; t++) {
         if (t == s) continue;
@@ -169,9 +179,9 @@ __global__ __launch_bounds__(256) void k_reorder(
         rank += (idt & 0x3fffffffu) < (id & 0x3fffffffu); // bits 30/31: slab flags (sph_slab.h)
     }
     const int dst = cell.x + rank;
-    posmOut[dst] = posmIn[c];
-    velqOut[dst] = velqIn[c];
-    matOut[dst] = matIn[c];
+    posmOut[dst] = pm;
+    velqOut[dst] = vq;
+    matOut[dst] = mt;
     oidOut[dst] = id;
 }
 
@@ -228,17 +238,36 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
     }
     if (INTEGRATE) {
         const float r = m.radius;
+        // Swept: a particle that moves farther than half its radius takes
+        // the step in msub = ceil(|v| dt / (r/2)) pieces and meets the boxes after each, so that it
+        // is never carried through a box at least as thick as its radius (a centre that starts
+        // outside, or on a face, is then less than half the thickness deep: the nearest face is
+        // the one it came in through).  Piece s ends at xb + v (t_s - tb), (xb, tb) =
+        // where and when the particle last touched a box: without a contact the end position is
+        // x + v dt exactly.  The wave runs as many rounds as its fastest lane has pieces; a lane
+        // takes part in its own pieces only, so every particle sees the same sequence of tests as
+        // in a loop of its own (the oracle's).
+        float xb[3] = {x[0], x[1], x[2]}, tb = 0.f;
+        int msub = 1;
+        if (nboxes > 0 && live) {
+            const float sp = sqrtf(dot3f(v, v)) * dt, piece = 0.5f * r;
+            if (sp > piece) msub = (int)fminf(ceilf(sp / piece), (float)SPH_MAX_SUBSTEPS);
+        }
+        int mw = msub;
 #pragma unroll
-        for (int a = 0; a < 3; a++) x[a] = x[a] + v[a] * dt;
+        for (int d = 32; d >= 1; d >>= 1) mw = max(mw, __shfl_xor(mw, d, 64));
+        mw = __builtin_amdgcn_readfirstlane(mw);
+#pragma unroll
+        for (int a = 0; a < 3; a++) x[a] = xb[a] + v[a] * dt;
         // Broadphase: the particles of a wave are neighbours in the sorted order (a few cells), so
         // the wave's own bounds (spheres included) are tested against each box's world AABB with
         // scalar compares and the whole wave skips a box it cannot touch.  Exact: a box that is
         // skipped would have changed nothing; the bounds are taken again after any push-out.
         float wmin[3], wmax[3];
-        auto wave_bounds = [&]() {
+        auto wave_bounds = [&](bool act, const float *lo3, const float *hi3) {
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                float lo = live ? x[a] - r : 3.0e38f, hi = live ? x[a] + r : -3.0e38f;
+                float lo = act ? lo3[a] - r : 3.0e38f, hi = act ? hi3[a] + r : -3.0e38f;
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) {
                     lo = fminf(lo, __shfl_xor(lo, d, 64));
@@ -248,11 +277,42 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
                 wmax[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hi)));
             }
         };
-        if (nboxes > 0) wave_bounds();
         auto misses = [&](const float4 lo, const float4 hi) { // wave-uniform (scalar operands)
             return wmax[0] < lo.x || wmin[0] > hi.x || wmax[1] < lo.y || wmin[1] > hi.y ||
                    wmax[2] < lo.z || wmin[2] > hi.z;
         };
+        if (nboxes <= 0) mw = 0;
+        if (mw > 1) {
+            // a wave with pieces to take: if nothing lies within the bounds of its particles'
+            // whole paths, no piece of any lane can touch a box and the end positions stand
+            float plo[3], phi[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                plo[a] = fminf(xb[a], x[a]);
+                phi[a] = fmaxf(xb[a], x[a]);
+            }
+            wave_bounds(live, plo, phi);
+            bool any = false;
+            for (int k = 0; k < nboxes && !any; k++) {
+                if ((k & (SPH_BOX_CHUNK - 1)) == 0 &&
+                    misses(chunkAabb[2 * (k / SPH_BOX_CHUNK)], chunkAabb[2 * (k / SPH_BOX_CHUNK) + 1])) {
+                    k += SPH_BOX_CHUNK - 1;
+                    continue;
+                }
+                any = !misses(boxAabb[2 * k], boxAabb[2 * k + 1]);
+            }
+            if (!any) mw = 0;
+        }
+        for (int s = 1; s <= mw; s++) {
+        const bool act = live && s <= msub;
+        const float ts = s == msub ? dt : dt * ((float)s / (float)msub);
+        if (act) {
+            const float tau = ts - tb;
+#pragma unroll
+            for (int a = 0; a < 3; a++) x[a] = xb[a] + v[a] * tau;
+        }
+        bool touchedAny = false;
+        wave_bounds(act, x, x);
         // two levels, in index order (the order of the boxes is part of the result): chunks of
         // SPH_BOX_CHUNK consecutive boxes by their joint bounds, then the boxes of a chunk
         for (int k = 0; k < nboxes; k++) {
@@ -267,7 +327,7 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
             const DevBox &bx = boxes[k];
             float imp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             bool pushed = false, touched = false;
-            if (live) {
+            if (act) {
                 const float d[3] = {x[0] - bx.c[0], x[1] - bx.c[1], x[2] - bx.c[2]};
                 float p[3], delta[3], nl[3] = {0.f, 0.f, 0.f}, pen = 0.f;
                 p[0] = (bx.R[0] * d[0] + bx.R[3] * d[1]) + bx.R[6] * d[2];
@@ -362,7 +422,14 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
                     if (lane_id() == 0) atomicAdd(&bodyImpulse[6 * k + a], t);
                 }
             }
-            if (__any(touched)) wave_bounds(); // positions were pushed out of the box
+            touchedAny = touchedAny || touched;
+            if (__any(touched)) wave_bounds(act, x, x); // positions were pushed out of the box
+        }
+        if (touchedAny) { // (act lanes only can have touched)
+#pragma unroll
+            for (int a = 0; a < 3; a++) xb[a] = x[a];
+            tb = ts;
+        }
         }
     }
     if (live) {

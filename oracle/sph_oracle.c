@@ -527,10 +527,12 @@ static inline void cross3(const float *a, const float *b, float *o)
 }
 
 /* particles: x += v*dt, then sphere(radius params[4i]) vs every box in order.
- * Swept: a particle that moves farther than its radius in the step takes the step in
- * m = ceil(|v| dt / r) equal pieces (at most ORC_MAX_SUBSTEPS) and is tested against the boxes
- * after each, so that its centre is never carried through a face: a piece no longer than r cannot
- * take a centre that is at least r outside a box to the inside of it.  The position of piece s is
+ * Swept: a particle that moves farther than half its radius in the step takes the step in
+ * m = ceil(|v| dt / (r/2)) equal pieces (at most ORC_MAX_SUBSTEPS) and is tested against the boxes
+ * after each, so that it is never carried through a box that is at least as thick as its radius:
+ * a piece of r/2 takes a centre that is outside the box (even one that starts ON a face, as the
+ * bottom layer of the demo lattice does) less than half the thickness deep, where the nearest face
+ * is still the one it came in through.  The position of piece s is
  * xb + v (t_s - tb), (xb, tb) = where and when the particle last touched a box (the start of the
  * step at first): without a contact the end position is x + v dt exactly as without pieces.
  * body_impulse: K x 6 floats (linear impulse, angular impulse about the centre), accumulated. */
@@ -551,8 +553,8 @@ ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMas
         }
         int msub = 1;
         if (nboxes > 0) {
-            float sp = sqrtf(dot3(v, v)) * dt;
-            if (sp > r) msub = (int)fminf(ceilf(sp / r), (float)ORC_MAX_SUBSTEPS);
+            float sp = sqrtf(dot3(v, v)) * dt, piece = 0.5f * r;
+            if (sp > piece) msub = (int)fminf(ceilf(sp / piece), (float)ORC_MAX_SUBSTEPS);
         }
         for (int s = 1; s <= msub; s++) {
         const float ts = s == msub ? dt : dt * ((float)s / (float)msub);

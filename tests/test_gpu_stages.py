@@ -138,6 +138,31 @@ def test_apply_force_and_integrate(ctx, oracle):
     assert_close(ctx.get_colliders(), oboxes, what="bodies")
 
 
+def test_fast_particles_do_not_tunnel(ctx, oracle):
+    """row I, swept: speeds of 1 to 3 wall thicknesses per step (|v| dt up to ~2.5; the discrete
+    test of round 2 let such particles through the 0.5-thick walls) against the oracle, and every
+    particle still inside the tank"""
+    sc = scene.demo_scene()
+    rng = np.random.default_rng(5)
+    sc.vel = rng.normal(0, 40.0, sc.pos.shape).astype(np.float32)
+    p = load_scene(ctx, sc, debug=0, colliders=True)
+    ctx.integrate(p)
+    opos, ovel, oimp = oracle.integrate_particles(sc.pos, sc.vel, sc.inv_mass, sc.params, sc.boxes,
+                                                  float(p.dt))
+    gpos, gvel = ctx.download()
+    speed = np.linalg.norm(sc.vel, axis=1) * float(p.dt)
+    assert (speed > 0.5).mean() > 0.5 and speed.max() > 2.0
+    assert_close(gpos, opos, what="position")
+    assert_close(gvel, ovel, what="velocity")
+    # the walls' mid-planes carry the boundary layer; inner faces 0.25 inside, centres a radius more
+    lo = sc.bpos.min(0) + 0.5 - 1e-3
+    hi = sc.bpos.max(0) - 0.5 + 1e-3
+    assert ((gpos > lo) & (gpos < hi)).all()
+    assert ((opos > lo) & (opos < hi)).all()
+    oboxes = oracle.integrate_bodies(sc.boxes, oimp, float(p.dt))
+    assert_close(ctx.get_colliders(), oboxes, rtol=1e-4, what="bodies")
+
+
 def test_seed_volume_matches_create_particles(ctx):
     """sph_seed_volume = FluidInitializeSystem.CreateParticles (:63-92) on the device: positions
     bit-exact against the host generator for the demo's water volume and a rotated, scaled wall;

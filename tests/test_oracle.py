@@ -136,6 +136,24 @@ def test_sphere_box_collision_analytic(oracle):
     np.testing.assert_allclose(v[0], [1.0, 3.0, 0.0], atol=1e-6)
 
 
+def test_fast_particles_do_not_tunnel(oracle):
+    """row I, swept: particles that would cross a 0.5-thick floor in one step (|v| dt = 1, 2 and 3
+    thicknesses; the discrete test of round 2 let them through) are stopped at its top face and
+    reflected; one that flies past the box keeps x + v dt to the bit"""
+    box = scene.static_box((0, -0.25, 0), (5, 0.25, 5))[None]
+    dt = 1 / 60.0
+    vy = np.array([-30.0, -60.0, -90.0, -90.0], np.float32)
+    pos = np.array([[0, 0.3, 0], [1, 0.9, 0], [2, 0.26, 0], [30, 0.3, 0]], np.float32)
+    vel = np.stack([np.full(4, 3.0, np.float32), vy, np.zeros(4, np.float32)], 1)
+    params = np.tile(np.array([[0.25, 1000, 256, 512]], np.float32), (4, 1))
+    p, v, imp = oracle.integrate_particles(pos, vel, np.full(4, 1 / 125.0), params, box, dt)
+    assert (p[:3, 1] >= 0.25 - 1e-6).all(), p          # above the floor, not below it
+    np.testing.assert_allclose(v[:3, 1], -0.5 * vy[:3], rtol=1e-6)   # e = 0.5
+    np.testing.assert_allclose(v[:3, 0], 3.0, rtol=1e-6)             # no friction
+    np.testing.assert_array_equal(p[3], pos[3] + vel[3] * np.float32(dt))
+    np.testing.assert_array_equal(v[3], vel[3])
+
+
 def test_dynamic_box_receives_the_reaction(oracle):
     box = scene.dynamic_box((0, -1.0, 0), (1, 1, 1), 100.0, lin_damping=0.0, ang_damping=0.0,
                             gravity_factor=0.0)[None]
