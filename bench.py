@@ -30,13 +30,18 @@ ALG_BYTES = {"keys": 20, "table": 6, "reorder": 52, "density": 20, "force": 44, 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)   # 50 warm-up + 200 timed
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="C3", choices=list(scene.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-round-trip", action="store_true")
     ap.add_argument("--no-stage-breakdown", action="store_true",
                     help="skip the second pass that times the stages other than the neighbour kernels")
+    ap.add_argument("--layout", default=None, choices=["z", "x"],
+                    help="N > 1 only.  z (default but for C4): weak scaling, every rank owns one --config "
+                         "sized block, flow along z, balanced slabs, fixed cuts.  x (default for C4, SURVEY "
+                         "8d): strong scaling, the --config scene itself split into N column ranges, dam "
+                         "break along x ACROSS the cuts, which move with the flow")
     ap.add_argument("--cpu-baseline-config", default=None,
                     help="workload of the bounded CPU sample (default: same as --config)")
     return ap.parse_args()
@@ -120,6 +125,7 @@ def main():
             dist.init_process_group(comm)
 
     sim = None
+    scaling = "weak"
     if world == 1:
         sc = scene.make_config(a.config, jittered=True)
         p = native.make_params(sc.grid_size, body_bounds=(sc.tank_min, sc.tank_max))
@@ -132,16 +138,30 @@ def main():
         workload = (f"{a.config} dam break: {sc.n} fluid + {sc.b} boundary particles + "
                     f"{len(sc.boxes)} box colliders, dt=1/60, h=1.0, jitter 0.02")
     else:
-        # weak scaling: every rank owns one --config sized block of a dam break that is `world`
-        # blocks wide in x and flows along z (every x column carries the same flow, so the slabs
-        # stay balanced); x-slab decomposition, halo 2 h, RCCL send/recv of device buffers
         from fluidsimulation_amd import slab
         nx, ny, nz, ci = scene.CONFIGS[a.config]
-        sc, ids = scene.dam_break_slab(nx * world, ny, nz, rank * nx, (rank + 1) * nx,
-                                       jitter_seed=scene.JITTER_SEED_BASE + ci, name=a.config)
-        p = native.make_params(sc.grid_size, body_bounds=(sc.tank_min, sc.tank_max))
+        layout = a.layout or ("x" if a.config == "C4" else "z")
         sp = 2.0 * float(scene.RADIUS)
-        edges = [-np.inf] + [r * nx * sp for r in range(1, world)] + [np.inf]
+        if layout == "z":
+            # weak scaling: every rank owns one --config sized block of a dam break that is `world`
+            # blocks wide in x and flows along z (every x column carries the same flow, so the slabs
+            # stay balanced); x-slab decomposition, halo 2 h, fixed cuts
+            sc, ids = scene.dam_break_slab(nx * world, ny, nz, rank * nx, (rank + 1) * nx,
+                                           jitter_seed=scene.JITTER_SEED_BASE + ci, name=a.config)
+            edges = [-np.inf] + [r * nx * sp for r in range(1, world)] + [np.inf]
+            sim_kw = {}
+            scaling = "weak"
+        else:
+            # strong scaling: the scene itself, water in the left third of the tank,
+            # split into `world` column ranges; the dam breaks along x, across the cuts, which move
+            # towards equal counts every step (at most one halo a step)
+            cols = [nx * r // world for r in range(world + 1)]
+            sc, ids = scene.dam_break_columns(nx, ny, nz, cols[rank], cols[rank + 1],
+                                              jitter_seed=scene.JITTER_SEED_BASE + ci, name=a.config)
+            edges = [-np.inf] + [cols[r] * sp for r in range(1, world)] + [np.inf]
+            sim_kw = dict(rebalance_every=1, domain=(0.0, 3.0 * nx * sp))
+            scaling = "strong"
+        p = native.make_params(sc.grid_size, body_bounds=(sc.tank_min, sc.tank_max))
         table, index = slab.material_table(sc.inv_mass, sc.params)
         ctx = native.Context(device=local, timings=2)   # events around the two neighbour kernels only
         ctx.set_boundary(sc.bpos, sc.bparams)
@@ -149,20 +169,47 @@ def main():
         face = ny * nz * 4            # lattice sites within the 2 h halo of one face at t = 0
         # the fluid piles up against the far wall while it runs: room for 3x the rest-state halo
         # population in every exchange buffer, and for two generations of ghosts from both sides
+        # (with moving cuts a rank may also come to own more than it started with)
         buf = 12 * face
         ctx.slab_upload(sc.pos, sc.vel, index, ids, table, sc.grid_size,
-                        capacity=sc.n + 4 * buf)
+                        capacity=sc.n + 4 * buf + (sc.n // 2 if layout == "x" else 0))
         be = slab.HipSlabBackend(ctx, p, f"cuda:{local}", buffer_records=buf)
-        if os.environ.get("SPH_BENCH_EXCHANGE", "torch") == "native":
-            # the library's own RCCL communicator instead of torch.distributed's send/recv
-            be.init_native_exchange(rank, world)
-        sim = slab.SlabSimulation(be, edges, halo=2.0 * sc.grid_size)
+        # Transport of the records.  Over RCCL the default is the library's own communicator
+        # (sph_slab_exchange: what a host without a communication layer, the C# host, would call);
+        # SPH_BENCH_EXCHANGE=torch selects torch.distributed's send/recv of the same buffers.  The
+        # gloo rehearsal (several ranks on one GPU, which RCCL refuses) always goes through torch.
+        want_native = dist.get_backend() == "nccl" and os.environ.get("SPH_BENCH_EXCHANGE", "native") == "native"
+        transport = f"torch.distributed {dist.get_backend()} send/recv (batch_isend_irecv)"
+        if want_native:
+            import torch
+            err = ""
+            try:
+                be.init_native_exchange(rank, world)
+            except Exception as e:       # every rank must agree on the transport
+                err = str(e)
+            ok = torch.tensor([0 if err else 1], device=f"cuda:{local}")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if bool(ok.item()):
+                transport = "rccl ncclSend/ncclRecv inside libsphfluid (sph_slab_exchange, the library's own communicator)"
+            else:
+                if be.native_exchange:
+                    ctx.slab_comm_destroy()
+                    be.native_exchange = False
+                print(f"bench.py rank {rank}: native RCCL exchange unavailable ({err or 'another rank failed'}); "
+                      f"falling back to torch.distributed", file=sys.stderr)
+                transport += " [library's own RCCL communicator failed to open]"
+        sim = slab.SlabSimulation(be, edges, halo=2.0 * sc.grid_size, **sim_kw)
         n_local = sc.n
-        parallelism = (f"x-slab decomposition over {world} ranks, ghosts within 2h + ownership "
-                       f"transfers by {dist.get_backend()} send/recv every step")
-        workload = (f"{world} x {a.config} block dam break along z: {sc.n} fluid particles per "
-                    f"GPU ({world * sc.n} total), {sc.b} boundary particles + {len(sc.boxes)} "
-                    f"static boxes per rank, dt=1/60, h=1.0, jitter 0.02")
+        parallelism = (f"x-slab decomposition over {world} ranks ({scaling} scaling), ghosts within 2h + "
+                       f"ownership transfers every step; transport: {transport}")
+        if layout == "z":
+            workload = (f"{world} x {a.config} block dam break along z: {sc.n} fluid particles per "
+                        f"GPU ({world * sc.n} total), {sc.b} boundary particles + {len(sc.boxes)} "
+                        f"static boxes per rank, dt=1/60, h=1.0, jitter 0.02, fixed cuts")
+        else:
+            workload = (f"{a.config} dam break along x split into {world} column ranges with moving "
+                        f"cuts: {nx * ny * nz} fluid particles in total, {sc.b} boundary particles + "
+                        f"{len(sc.boxes)} static boxes on every rank, dt=1/60, h=1.0, jitter 0.02")
 
     def run(nsteps):
         if sim is None:
@@ -192,6 +239,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tm = ctx.timings()
+    total_particles = n_local * world
+    if sim is not None and scaling == "strong":
+        total_particles = scene.CONFIGS[a.config][0] * scene.CONFIGS[a.config][1] * scene.CONFIGS[a.config][2]
     if sim is None:
         pos, vel = ctx.download()
         slab_info = None
@@ -235,12 +285,16 @@ def main():
         achieved = alg[dom] * n / (stage_ms[dom] * 1e-3) / 1e9
         step_alg = sum(alg.values())
         out = {
-            "metric": "particle-updates/sec per SPH step", "value": world * n * a.steps / elapsed,
+            "metric": "particle-updates/sec per SPH step", "value": total_particles * a.steps / elapsed,
             "unit": "particle-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "particles_per_gpu": n, "parallelism": parallelism,
-                       "comm_backend": (dist.get_backend() if dist is not None else "none")},
+            "config": {"workload": workload + f"; steps {a.warmup}..{a.warmup + a.steps} of the collapse",
+                       "particles_per_gpu": n, "parallelism": parallelism,
+                       "comm_backend": (dist.get_backend() if dist is not None else "none"),
+                       "exchange": ("none" if sim is None else
+                                    ("libsphfluid sph_slab_exchange (RCCL)" if be.native_exchange
+                                     else "torch.distributed send/recv"))},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, a.config, n) if world == 1 else None,
@@ -274,14 +328,18 @@ def main():
                 t1 = time.perf_counter()
                 for _ in range(frames):
                     c2.step_inplace(p, hp, hv, sc.inv_mass, sc.params)
-                return (time.perf_counter() - t1) / frames
+                dt_ = (time.perf_counter() - t1) / frames
+                st = c2.pin_stats()
+                c2.unpin_host()          # hp / hv go away with this frame
+                return dt_, st
             ctx.close()
             with native.Context(device=local) as c2:
-                rt = round_trip(c2, 3)
+                rt, _ = round_trip(c2, 3)
             with native.Context(device=local, pin_host_arrays=True) as c2:
-                rtp = round_trip(c2, 3)
+                rtp, pin = round_trip(c2, 3)
             out["host_round_trip"] = {"ms_per_step": rt * 1e3, "value": n / rt,
                                       "ms_per_step_pinned": rtp * 1e3, "value_pinned": n / rtp,
+                                      "pinned_arrays": pin,
                                       "unit": "particle-updates/s",
                                       "what": "sph_step: upload 24 B + step + download 24 B per "
                                               "particle on the caller's arrays, 3 frames after a "

@@ -171,13 +171,27 @@ __global__ __launch_bounds__(256) void k_reorder(
     __syncthreads();
     if (s >= n) return;
     const int2 cell = table[key];
+    const uint32_t me = id & 0x3fffffffu; // bits 30/31: slab flags (sph_slab.h)
     int rank = 0;
-    for (int t = cell.x; t < cell.y; t++) {
-        if (t == s) continue;
-        const int rel = t - blockBase;
-        const uint32_t idt = (rel >= 0 && rel < 256) ? ids[rel] : oidIn[perm[t]];
-        rank += (idt & 0x3fffffffu) < (id & 0x3fffffffu); // bits 30/31: slab flags (sph_slab.h)
-    }
+    // cell mates inside this block: their ids are in LDS
+    const int lo = max(cell.x, blockBase), hi = min(cell.y, blockBase + 256);
+    for (int t = lo; t < hi; t++) rank += (ids[t - blockBase] & 0x3fffffffu) < me; // (never < itself)
+    // cell mates outside it (a cell that straddles a block boundary; every mate but 256 of a
+    // crowded cell): two dependent loads each, eight in flight at a time -- one after the other
+    // they cost a crowded step 3 ms (hundreds of particles per cell while a deep column lands)
+    auto outside = [&](int a, int b) {
+        for (int t0 = a; t0 < b; t0 += 8) {
+            uint32_t pv[8], iv[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) pv[q] = perm[min(t0 + q, b - 1)];
+#pragma unroll
+            for (int q = 0; q < 8; q++) iv[q] = oidIn[pv[q]];
+#pragma unroll
+            for (int q = 0; q < 8; q++) rank += (t0 + q < b && (iv[q] & 0x3fffffffu) < me) ? 1 : 0;
+        }
+    };
+    outside(cell.x, min(cell.y, blockBase));
+    outside(max(cell.x, blockBase + 256), cell.y);
     const int dst = cell.x + rank;
     posmOut[dst] = pm;
     velqOut[dst] = vq;
@@ -248,6 +262,7 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
         // takes part in its own pieces only, so every particle sees the same sequence of tests as
         // in a loop of its own (the oracle's).
         float xb[3] = {x[0], x[1], x[2]}, tb = 0.f;
+        float xprev[3] = {x[0], x[1], x[2]}; // end of the piece before (start of the step at first)
         int msub = 1;
         if (nboxes > 0 && live) {
             const float sp = sqrtf(dot3f(v, v)) * dt, piece = 0.5f * r;
@@ -306,6 +321,7 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
         for (int s = 1; s <= mw; s++) {
         const bool act = live && s <= msub;
         const float ts = s == msub ? dt : dt * ((float)s / (float)msub);
+        const float xs[3] = {xprev[0], xprev[1], xprev[2]}; // where the piece starts: outside every static box
         if (act) {
             const float tau = ts - tb;
 #pragma unroll
@@ -313,8 +329,15 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
         }
         bool touchedAny = false;
         wave_bounds(act, x, x);
-        // two levels, in index order (the order of the boxes is part of the result): chunks of
-        // SPH_BOX_CHUNK consecutive boxes by their joint bounds, then the boxes of a chunk
+        // Every box in index order (the order of the boxes is part of the result); then, if that
+        // pushed the particle, the STATIC boxes once more: a push out of one box can end inside a
+        // box that was tested before it, and a particle may spend a step inside a moving box but
+        // never inside a wall (from beyond a wall's mid-plane the way out is the far side).
+        // Two levels: chunks of SPH_BOX_CHUNK consecutive boxes by their joint bounds, then the
+        // boxes of a chunk.
+        for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1 && !__any(touchedAny)) break;
+        const bool again = pass == 1 && touchedAny; // (lanes the first pass did not push: unchanged)
         for (int k = 0; k < nboxes; k++) {
             if ((k & (SPH_BOX_CHUNK - 1)) == 0) {
                 const int ch = k / SPH_BOX_CHUNK;
@@ -325,9 +348,10 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
             }
             if (misses(boxAabb[2 * k], boxAabb[2 * k + 1])) continue;
             const DevBox &bx = boxes[k];
+            if (pass == 1 && bx.dynamic) continue;
             float imp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             bool pushed = false, touched = false;
-            if (act) {
+            if (act && (pass == 0 || again)) {
                 const float d[3] = {x[0] - bx.c[0], x[1] - bx.c[1], x[2] - bx.c[2]};
                 float p[3], delta[3], nl[3] = {0.f, 0.f, 0.f}, pen = 0.f;
                 p[0] = (bx.R[0] * d[0] + bx.R[3] * d[1]) + bx.R[6] * d[2];
@@ -347,6 +371,10 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
                         contact = true;
                     }
                 } else {
+                    // centre inside the box: out through the nearest face -- but out of a STATIC
+                    // box through the face the piece started beyond, if there is one (a push out of
+                    // a moving box can carry a particle past a wall's mid-plane, from where the
+                    // nearest face is the far one: nothing ever crosses a static box this way)
                     int best = 0;
                     float bestd = bx.he[0] - fabsf(p[0]);
 #pragma unroll
@@ -354,9 +382,33 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
                         const float da = bx.he[a] - fabsf(p[a]);
                         if (da < bestd) { bestd = da; best = a; }
                     }
+                    float sgn = 0.f;
 #pragma unroll
                     for (int a = 0; a < 3; a++)
-                        if (a == best) nl[a] = p[a] < 0.f ? -1.f : 1.f;
+                        if (a == best) sgn = p[a] < 0.f ? -1.f : 1.f;
+                    if (!bx.dynamic) {
+                        const float ds[3] = {xs[0] - bx.c[0], xs[1] - bx.c[1], xs[2] - bx.c[2]};
+                        float ps[3];
+                        ps[0] = (bx.R[0] * ds[0] + bx.R[3] * ds[1]) + bx.R[6] * ds[2];
+                        ps[1] = (bx.R[1] * ds[0] + bx.R[4] * ds[1]) + bx.R[7] * ds[2];
+                        ps[2] = (bx.R[2] * ds[0] + bx.R[5] * ds[1]) + bx.R[8] * ds[2];
+                        float beste = 0.f;
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            const float ex = fabsf(ps[a]) - bx.he[a];
+                            if (ex > beste) {
+                                beste = ex;
+                                best = a;
+                                sgn = ps[a] < 0.f ? -1.f : 1.f;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+                        if (a == best) {
+                            nl[a] = sgn;
+                            bestd = bx.he[a] - sgn * p[a];
+                        }
                     pen = bestd + r;
                     contact = true;
                 }
@@ -425,10 +477,15 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
             touchedAny = touchedAny || touched;
             if (__any(touched)) wave_bounds(act, x, x); // positions were pushed out of the box
         }
+        }
         if (touchedAny) { // (act lanes only can have touched)
 #pragma unroll
             for (int a = 0; a < 3; a++) xb[a] = x[a];
             tb = ts;
+        }
+        if (act) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) xprev[a] = x[a];
         }
         }
     }

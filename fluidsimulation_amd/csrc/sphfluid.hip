@@ -2139,6 +2139,15 @@ const char *rccl_open()
         if (r_ != ncclSuccess)                                                                   \
             return fail(c, SPH_E_DEVICE, "%s: %s", #expr, g_rccl.GetErrorString(r_));            \
     } while (0)
+// the same inside ncclGroupStart .. ncclGroupEnd: the group is closed before the error is returned
+#define RCCLCHK_IN_GROUP(c, expr)                                                                \
+    do {                                                                                         \
+        ncclResult_t r_ = (expr);                                                                \
+        if (r_ != ncclSuccess) {                                                                 \
+            (void)g_rccl.GroupEnd();                                                             \
+            return fail(c, SPH_E_DEVICE, "%s: %s", #expr, g_rccl.GetErrorString(r_));            \
+        }                                                                                        \
+    } while (0)
 
 int sph_slab_comm_unique_id(uint8_t *id_out, int32_t cap)
 {
@@ -2211,12 +2220,12 @@ int sph_slab_exchange(SphCtx *c, float xlo, float xhi, float halo, int32_t count
     if (hasL || hasR) {
         RCCLCHK(c, g_rccl.GroupStart());
         if (hasL) {
-            RCCLCHK(c, g_rccl.Send(c->slabCounters.p, 16, ncclUint8, left, c->comm, c->stream));
-            RCCLCHK(c, g_rccl.Recv(c->xhdr.p, 16, ncclUint8, left, c->comm, c->stream));
+            RCCLCHK_IN_GROUP(c, g_rccl.Send(c->slabCounters.p, 16, ncclUint8, left, c->comm, c->stream));
+            RCCLCHK_IN_GROUP(c, g_rccl.Recv(c->xhdr.p, 16, ncclUint8, left, c->comm, c->stream));
         }
         if (hasR) {
-            RCCLCHK(c, g_rccl.Send(c->slabCounters.p, 16, ncclUint8, right, c->comm, c->stream));
-            RCCLCHK(c, g_rccl.Recv(c->xhdr.p + 4, 16, ncclUint8, right, c->comm, c->stream));
+            RCCLCHK_IN_GROUP(c, g_rccl.Send(c->slabCounters.p, 16, ncclUint8, right, c->comm, c->stream));
+            RCCLCHK_IN_GROUP(c, g_rccl.Recv(c->xhdr.p + 4, 16, ncclUint8, right, c->comm, c->stream));
         }
         RCCLCHK(c, g_rccl.GroupEnd());
     }
@@ -2234,11 +2243,29 @@ int sph_slab_exchange(SphCtx *c, float xlo, float xhi, float halo, int32_t count
     const uint32_t sendN[2] = {hasL ? h[0] : 0u, hasR ? h[1] : 0u};
     const uint32_t recvN[2] = {hasL ? h[4 + 1] : 0u, hasR ? h[8 + 0] : 0u};
     const uint32_t recvT[2] = {hasL ? h[4 + 3] : 0u, hasR ? h[8 + 2] : 0u};
+    // Room for the messages and for what arrives.  Everything that can fail locally is done HERE,
+    // before this rank commits to the trade of the records: sph_slab_exchange_reserve sizes the
+    // buffers up front so that a step normally allocates nothing; beyond the reserve they grow
+    // (a hipFree / hipMalloc in the middle of the run).  A rank that fails here returns while its
+    // neighbours wait in ncclRecv -- an out-of-memory condition ends the run on every rank, the
+    // launcher's job; it cannot be reported to the peers without a second header trade per step.
     const uint32_t capSend = std::max(std::max(h[0], h[1]), 1u);
     int rc = SPH_OK;
     for (int s = 0; s < 2 && !rc; s++) {
         rc = ensure(c, c->xsend[s], 2 * (size_t)capSend);
         if (!rc) rc = ensure(c, c->xrecv[s], 2 * (size_t)std::max(recvN[s], 1u));
+    }
+    if (!rc && (long long)c->n + recvN[0] + recvN[1] > (1ll << 30))
+        rc = fail(c, SPH_E_TOOLARGE, "slab beyond 2^30 records");
+    if (!rc && c->n + (int)(recvN[0] + recvN[1]) > c->slabCap) { // (as sph_slab_import would, later)
+        const int cur0 = c->cur, n0 = c->n;
+        const size_t want = (size_t)n0 + recvN[0] + recvN[1] + ((size_t)n0 + recvN[0] + recvN[1]) / 4 + 1024;
+        rc = grow_keep(c, c->posm[cur0], want, (size_t)n0);
+        if (!rc) rc = grow_keep(c, c->velq[cur0], want, (size_t)n0);
+        if (!rc) rc = grow_keep(c, c->mat[cur0], want, (size_t)n0);
+        if (!rc) rc = grow_keep(c, c->oid[cur0], want, (size_t)n0);
+        if (!rc) rc = ensure_fluid(c, (int)want);
+        if (!rc) c->slabCap = (int)want;
     }
     if (rc) return rc;
     const uint32_t cap = (uint32_t)std::min<size_t>(std::min(c->xsend[0].cap, c->xsend[1].cap) / 2, 1u << 30);
@@ -2258,10 +2285,10 @@ int sph_slab_exchange(SphCtx *c, float xlo, float xhi, float halo, int32_t count
     // 4. the records
     if (sendN[0] + sendN[1] + recvN[0] + recvN[1] > 0) {
         RCCLCHK(c, g_rccl.GroupStart());
-        if (sendN[0]) RCCLCHK(c, g_rccl.Send(c->xsend[0].p, (size_t)sendN[0] * 32, ncclUint8, left, c->comm, c->stream));
-        if (sendN[1]) RCCLCHK(c, g_rccl.Send(c->xsend[1].p, (size_t)sendN[1] * 32, ncclUint8, right, c->comm, c->stream));
-        if (recvN[0]) RCCLCHK(c, g_rccl.Recv(c->xrecv[0].p, (size_t)recvN[0] * 32, ncclUint8, left, c->comm, c->stream));
-        if (recvN[1]) RCCLCHK(c, g_rccl.Recv(c->xrecv[1].p, (size_t)recvN[1] * 32, ncclUint8, right, c->comm, c->stream));
+        if (sendN[0]) RCCLCHK_IN_GROUP(c, g_rccl.Send(c->xsend[0].p, (size_t)sendN[0] * 32, ncclUint8, left, c->comm, c->stream));
+        if (sendN[1]) RCCLCHK_IN_GROUP(c, g_rccl.Send(c->xsend[1].p, (size_t)sendN[1] * 32, ncclUint8, right, c->comm, c->stream));
+        if (recvN[0]) RCCLCHK_IN_GROUP(c, g_rccl.Recv(c->xrecv[0].p, (size_t)recvN[0] * 32, ncclUint8, left, c->comm, c->stream));
+        if (recvN[1]) RCCLCHK_IN_GROUP(c, g_rccl.Recv(c->xrecv[1].p, (size_t)recvN[1] * 32, ncclUint8, right, c->comm, c->stream));
         RCCLCHK(c, g_rccl.GroupEnd());
     }
     // 5. append what arrived (queued behind the receives on the same stream)
@@ -2272,6 +2299,22 @@ int sph_slab_exchange(SphCtx *c, float xlo, float xhi, float halo, int32_t count
         counts[1] = (int32_t)sendN[1];
         counts[2] = (int32_t)recvN[0];
         counts[3] = (int32_t)recvN[1];
+    }
+    return SPH_OK;
+}
+
+// Sizes the exchange buffers of sph_slab_exchange for `records` records a side (32 bytes each, four
+// buffers), so that the steps that follow allocate nothing as long as no message is larger.
+int sph_slab_exchange_reserve(SphCtx *c, int32_t records)
+{
+    if (!c) return SPH_E_INVALID;
+    if (records < 0) return fail(c, SPH_E_INVALID, "sph_slab_exchange_reserve: negative size");
+    if (int rc_ = use_device(c)) return rc_;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < 2; s++) {
+        int rc = ensure(c, c->xsend[s], 2 * (size_t)std::max(records, 1), false);
+        if (!rc) rc = ensure(c, c->xrecv[s], 2 * (size_t)std::max(records, 1), false);
+        if (rc) return rc;
     }
     return SPH_OK;
 }

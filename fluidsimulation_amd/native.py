@@ -41,6 +41,7 @@ EXPORTS = [
     "sph_slab_upload", "sph_slab_pack", "sph_slab_import", "sph_slab_counts", "sph_slab_download",
     "sph_slab_step_particles", "sph_slab_get_impulses", "sph_slab_step_bodies",
     "sph_slab_comm_unique_id", "sph_slab_comm_init", "sph_slab_exchange", "sph_slab_comm_destroy",
+    "sph_slab_exchange_reserve",
 ]
 
 
@@ -136,6 +137,7 @@ def load():
     lib.sph_slab_comm_init.argtypes = [vp, i32, i32, vp, i32]
     lib.sph_slab_exchange.argtypes = [vp, f32, f32, f32, C.POINTER(i32 * 4)]
     lib.sph_slab_comm_destroy.argtypes = [vp]
+    lib.sph_slab_exchange_reserve.argtypes = [vp, i32]
     for name in EXPORTS:
         if name not in ("sph_last_error", "sph_find_grid_size"):
             getattr(lib, name).restype = C.c_int
@@ -444,6 +446,9 @@ class Context:
         counts = (C.c_int32 * 4)()
         self._chk(self.lib.sph_slab_exchange(self.h, xlo, xhi, halo, C.byref(counts)))
         return list(counts)
+
+    def slab_exchange_reserve(self, records):
+        self._chk(self.lib.sph_slab_exchange_reserve(self.h, int(records)))
 
     def slab_comm_destroy(self):
         self._chk(self.lib.sph_slab_comm_destroy(self.h))

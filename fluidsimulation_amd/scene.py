@@ -294,6 +294,49 @@ def dam_break_slab(nx, ny, nz, col0, col1, jitter_seed=None, margin_cols=8, ampl
     return sc, gid.astype(np.uint32)
 
 
+def dam_break_columns(nx, ny, nz, col0, col1, jitter_seed=None, amplitude=0.02, name=""):
+    """The fluid columns col0 <= x-index < col1 of dam_break(nx, ny, nz) -- the SURVEY 8d tank,
+    water in the left third, flow along x, ACROSS the cuts of an x-slab decomposition -- with the
+    whole tank's boundary layers and wall boxes (the cuts move with the flow, so every rank keeps
+    them all).  Returns (Scene, global ids); ids and jitter depend only on the global lattice
+    index: the union over any partition of the columns is dam_break(nx, ny, nz, jitter_seed)."""
+    sp = F32(2) * RADIUS
+    xs = np.arange(col0, col1, dtype=np.int64)
+    zz, yy, xx = np.meshgrid(np.arange(nz, dtype=np.int64), np.arange(ny, dtype=np.int64), xs,
+                             indexing="ij")
+    gid = ((zz * ny + yy) * nx + xx).ravel()
+    pos = np.stack([(xx.ravel().astype(F32) + F32(0.5)) * sp,
+                    (yy.ravel().astype(F32) + F32(0.5)) * sp,
+                    (zz.ravel().astype(F32) + F32(0.5)) * sp], axis=1).astype(F32)
+    if jitter_seed is not None:
+        idx3 = (gid[:, None] * 3 + np.arange(3, dtype=np.int64)[None, :])
+        u = splitmix64_at(idx3, jitter_seed)
+        pos = (pos + (u * F32(2) - F32(1)) * F32(amplitude)).astype(F32)
+    tx, ty, tz = 3 * nx, ny, nz
+    L = np.array([tx, ty, tz], F32) * sp
+    faces = [
+        _plane(ty, tz, 0, F32(0), sp), _plane(ty, tz, 0, L[0], sp),
+        _plane(tx, tz, 1, F32(0), sp), _plane(tx, tz, 1, L[1], sp),
+        _plane(tx, ty, 2, F32(0), sp), _plane(tx, ty, 2, L[2], sp),
+    ]
+    bpos = np.concatenate(faces, axis=0)
+    half = L * F32(0.5)
+    t = F32(0.25)
+    boxes = []
+    for a in range(3):
+        for side in (0, 1):
+            c = half.copy()
+            c[a] = L[a] + t if side else -t
+            he = half.copy() + F32(2) * t
+            he[a] = t
+            boxes.append(static_box(c, he))
+    params, inv_mass = _fluid_arrays(len(pos))
+    sc = Scene(pos=pos, vel=np.zeros_like(pos), inv_mass=inv_mass, params=params, bpos=bpos,
+               bparams=_boundary_params(len(bpos)), grid_size=float(RADIUS * KERNEL_RADIUS_RATE),
+               boxes=np.stack(boxes).astype(F32), tank_min=np.zeros(3, F32), tank_max=L, name=name)
+    return sc, gid.astype(np.uint32)
+
+
 CONFIGS = {
     # name: (nx, ny, nz, config index for the jitter seed)
     "C1": (12, 20, 20, 0),

@@ -117,6 +117,9 @@ class HipSlabBackend:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
                                        group=group)
         self.ctx.slab_comm_init(rank, world, box[0])
+        # the library's own send / receive buffers, sized like this backend's: no allocation
+        # inside a step unless a message outgrows them
+        self.ctx.slab_exchange_reserve(self.cap)
         self.native_exchange = True
 
     def _alloc(self, cap):

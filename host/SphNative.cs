@@ -163,6 +163,7 @@ public static unsafe class SphNative
     [DllImport(Lib)] public static extern int sph_slab_comm_init(IntPtr ctx, int rank, int world, byte* uniqueId, int uniqueIdBytes);
     [DllImport(Lib)] public static extern int sph_slab_comm_unique_id(byte* uniqueIdOut, int capBytes);
     [DllImport(Lib)] public static extern int sph_slab_exchange(IntPtr ctx, float xlo, float xhi, float halo, int* counts4);
+    [DllImport(Lib)] public static extern int sph_slab_exchange_reserve(IntPtr ctx, int records);
     [DllImport(Lib)] public static extern int sph_slab_comm_destroy(IntPtr ctx);
 
     public static string LastError(IntPtr ctx) => Marshal.PtrToStringAnsi(sph_last_error(ctx));

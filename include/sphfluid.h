@@ -340,6 +340,9 @@ SPH_API int sph_slab_comm_unique_id(uint8_t *id_out, int32_t cap);
 SPH_API int sph_slab_comm_init(SphCtx *ctx, int32_t rank, int32_t world, const uint8_t *unique_id,
                                int32_t id_bytes);
 SPH_API int sph_slab_exchange(SphCtx *ctx, float xlo, float xhi, float halo, int32_t counts[4]);
+/* room for `records` records a side in the library's send / receive buffers, allocated now: the
+ * exchanges that follow allocate nothing unless a message is larger (then the buffers grow) */
+SPH_API int sph_slab_exchange_reserve(SphCtx *ctx, int32_t records);
 SPH_API int sph_slab_comm_destroy(SphCtx *ctx);
 /* counts = records resident, owned, live ghosts, dead ghosts */
 SPH_API int sph_slab_counts(SphCtx *ctx, int32_t counts[4]);

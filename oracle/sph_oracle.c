@@ -537,6 +537,11 @@ static inline void cross3(const float *a, const float *b, float *o)
  * step at first): without a contact the end position is x + v dt exactly as without pieces.
  * body_impulse: K x 6 floats (linear impulse, angular impulse about the centre), accumulated. */
 #define ORC_MAX_SUBSTEPS 64
+static int box_dynamic_(const OrcBox *bx)
+{
+    return bx->invMass != 0.0f || bx->invInertia[0] != 0.0f || bx->invInertia[1] != 0.0f ||
+           bx->invInertia[2] != 0.0f;
+}
 ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMass,
                                      const float *params, int n, const OrcBox *boxes, int nboxes,
                                      float dt, float particleRestitution, float *body_impulse)
@@ -560,10 +565,17 @@ ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMas
         const float ts = s == msub ? dt : dt * ((float)s / (float)msub);
         const float tau = ts - tb;
         int touched = 0;
+        const float xs[3] = {x[0], x[1], x[2]}; /* where the piece starts: outside every static box */
         for (int a = 0; a < 3; a++) x[a] = xb[a] + v[a] * tau;
+        /* every box in order; then, if that pushed the particle, the static boxes once more: a
+         * push out of one box can end inside a box tested before it, and a particle may spend a
+         * step inside a moving box but never inside a wall */
+        for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1 && !touched) break;
         for (int k = 0; k < nboxes; k++) {
             const OrcBox *bx = &boxes[k];
             const float *m = mats + 9 * k;
+            if (pass == 1 && box_dynamic_(bx)) continue;
             float d[3] = {x[0] - bx->center[0], x[1] - bx->center[1], x[2] - bx->center[2]};
             float p[3], q[3], delta[3], nl[3] = {0, 0, 0}, pen;
             mat_tmul(m, d, p);
@@ -577,14 +589,31 @@ ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMas
                 float dist = sqrtf(dist2);
                 for (int a = 0; a < 3; a++) nl[a] = delta[a] / dist;
                 pen = r - dist;
-            } else { /* centre inside the box: leave through the nearest face */
+            } else { /* centre inside the box: leave through the nearest face; a STATIC box
+                      * through the face the piece started beyond, if there is one (a push out of a
+                      * moving box can carry a particle past a wall's mid-plane) */
                 int best = 0;
                 float bestd = bx->halfExtents[0] - fabsf(p[0]);
                 for (int a = 1; a < 3; a++) {
                     float da = bx->halfExtents[a] - fabsf(p[a]);
                     if (da < bestd) { bestd = da; best = a; }
                 }
-                nl[best] = p[best] < 0.0f ? -1.0f : 1.0f;
+                float sgn = p[best] < 0.0f ? -1.0f : 1.0f;
+                if (!box_dynamic_(bx)) {
+                    float ds[3] = {xs[0] - bx->center[0], xs[1] - bx->center[1], xs[2] - bx->center[2]};
+                    float ps[3], beste = 0.0f;
+                    mat_tmul(m, ds, ps);
+                    for (int a = 0; a < 3; a++) {
+                        float ex = fabsf(ps[a]) - bx->halfExtents[a];
+                        if (ex > beste) {
+                            beste = ex;
+                            best = a;
+                            sgn = ps[a] < 0.0f ? -1.0f : 1.0f;
+                        }
+                    }
+                }
+                nl[best] = sgn;
+                bestd = bx->halfExtents[best] - sgn * p[best];
                 pen = bestd + r;
             }
             touched = 1;
@@ -623,6 +652,7 @@ ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMas
                         }
                 }
             }
+        }
         }
         if (touched) {
             for (int a = 0; a < 3; a++) xb[a] = x[a];

@@ -59,13 +59,19 @@ def main():
                               sc.bparams[bsel], sc.grid_size, static_boxes)
     else:
         from fluidsimulation_amd import native
-        ctx = native.Context(device=0)
+        # "hip": every rank on device 0, records through torch.distributed (gloo, host staging);
+        # "hip_native": one device per rank, records through the library's own RCCL communicator
+        # (sph_slab_exchange); torch.distributed (gloo) then only carries the unique id and the verdict
+        dev = rank if backend_name == "hip_native" else 0
+        ctx = native.Context(device=dev)
         ctx.set_boundary(sc.bpos[bsel], sc.bparams[bsel])
         ctx.set_colliders(static_boxes)
         ctx.slab_upload(sc.pos[own], sc.vel[own], index, ids, table, sc.grid_size,
                         capacity=2 * sc.n)
-        be = slab.HipSlabBackend(ctx, native.make_params(sc.grid_size), "cuda:0",
+        be = slab.HipSlabBackend(ctx, native.make_params(sc.grid_size), f"cuda:{dev}",
                                  buffer_records=sc.n, dynamic_bodies=bodies)
+        if backend_name == "hip_native":
+            be.init_native_exchange(rank, world)
     sim = slab.SlabSimulation(be, edges, halo=2.0 * h, rebalance_every=1 if rebalance else 0,
                               domain=(float(sc.pos[:, 0].min()), float(sc.pos[:, 0].max())),
                               max_shift=1.0 * h)

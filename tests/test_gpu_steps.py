@@ -40,14 +40,16 @@ def test_resident_steps_match_oracle(ctx, oracle, nsteps):
     assert_close(gpos, opos, rtol=rtol, what="position")
     assert_close(gvel, ovel, rtol=rtol, what="velocity")
     assert_close(ctx.get_colliders(), oboxes, rtol=rtol, what="bodies")
-    # element by element as well: coordinates with a floor of 1 % of h, velocity components with a
-    # floor of a fifth of the largest speed (a component is a sum of pair terms of the size of the
-    # largest one: below that floor it is cancellation, not signal)
-    # (one step; after ten the oracle itself moves by 6e-6 of the largest speed under a 1-ulp
-    # change of its input, profiles/r2_divergence_demo.txt: max-norm only)
+    # element by element as well: coordinates with a floor of 1 % of h; velocity components
+    # relative to themselves (1e-5) with an ABSOLUTE floor of 2e-6 of the largest speed.  That
+    # floor is half of what the oracle's own step-1 velocities move by when every input coordinate
+    # is changed by one ulp (4.19e-6 of the largest speed, profiles/r2_divergence_demo.txt, column
+    # "oracle(+1ulp)" at step 1): no implementation in fp32 can pin a component better than that.
+    # (One step; after ten the oracle moves by 6e-6 under the same change: max-norm only.)
     assert_close_elementwise(gpos, opos, rtol=rtol, floor=0.01, what="position, element-wise")
     if nsteps == 1:
-        assert_close_elementwise(gvel, ovel, rtol=rtol, floor=0.2 * float(np.abs(ovel).max()),
+        vmax = float(np.abs(ovel).max())
+        assert_close_elementwise(gvel, ovel, rtol=rtol, floor=2e-6 * vmax / rtol,
                                  what="velocity, element-wise")
 
 
@@ -333,8 +335,8 @@ def test_many_dynamic_boxes_two_rest_densities(ctx, oracle):
     gpos, gvel = ctx.download()
     gbox = ctx.get_colliders()
     opos, ovel, oboxes = oracle_steps(oracle, sc, nsteps, bounds=bounds)
-    assert_close(gpos, opos, rtol=2e-5, what="position")
-    assert_close(gvel, ovel, rtol=2e-5, what="velocity")
+    assert_close(gpos, opos, rtol=1e-5, what="position")
+    assert_close(gvel, ovel, rtol=1e-5, what="velocity")
     # bodies: the impulse sums arrive in atomic order (<= 1e-6 relative), three steps of them
     assert_close(gbox[:, 0:3], oboxes[:, 0:3], rtol=2e-5, what="body centre")
     assert_close(gbox[:, 3:7], oboxes[:, 3:7], rtol=2e-5, what="body rotation")
@@ -368,8 +370,8 @@ def test_a_thousand_colliders(ctx, oracle):
     gpos, gvel = ctx.download()
     gbox = ctx.get_colliders()
     opos, ovel, oboxes = oracle_steps(oracle, sc, nsteps, bounds=bounds)
-    assert_close(gpos, opos, rtol=2e-5, what="position")
-    assert_close(gvel, ovel, rtol=2e-5, what="velocity")
+    assert_close(gpos, opos, rtol=1e-5, what="position")
+    assert_close(gvel, ovel, rtol=1e-5, what="velocity")
     assert_close(gbox[:, 0:3], oboxes[:, 0:3], rtol=2e-5, what="body centre")
     assert_close(gbox[:, 10:16], oboxes[:, 10:16], rtol=1e-4, what="body velocities")
     # the obstacles did deflect particles: the run without them differs
