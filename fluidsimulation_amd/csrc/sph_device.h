@@ -47,7 +47,7 @@ struct Mat {
 
 // Box collider in the form the integrate kernel reads (row-major rotation, world = R*local)
 #define SPH_BOX_CHUNK 32 // boxes per broadphase chunk (consecutive indices)
-#define SPH_MAX_SUBSTEPS 64 // most pieces a fast particle's step is taken in (k_apply_integrate)
+#define SPH_MAX_SUBSTEPS 256 // most pieces a fast particle's step is taken in (k_apply_integrate)
 
 struct DevBox {
     float c[3];

@@ -253,25 +253,34 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
     if (INTEGRATE) {
         const float r = m.radius;
         // Swept: a particle that moves farther than half its radius takes
-        // the step in msub = ceil(|v| dt / (r/2)) pieces and meets the boxes after each, so that it
-        // is never carried through a box at least as thick as its radius (a centre that starts
-        // outside, or on a face, is then less than half the thickness deep: the nearest face is
-        // the one it came in through).  Piece s ends at xb + v (t_s - tb), (xb, tb) =
-        // where and when the particle last touched a box: without a contact the end position is
-        // x + v dt exactly.  The wave runs as many rounds as its fastest lane has pieces; a lane
-        // takes part in its own pieces only, so every particle sees the same sequence of tests as
-        // in a loop of its own (the oracle's).
+        // the step in pieces no longer than r/2 and meets the boxes after each, so that it is never
+        // carried through a box at least as thick as its radius (a centre that starts outside, or
+        // on a face, is then less than half the thickness deep: the nearest face is the one it
+        // came in through).  A piece ends at xb + v (t - tb), (xb, tb) = where and when the
+        // particle last touched a box: without a contact the end position is x + v dt exactly.
+        // The wave runs as many rounds as its lane with the most pieces; a lane takes part in its
+        // own pieces only, so every particle sees the same sequence of tests as in a loop of its
+        // own (the oracle's).
         float xb[3] = {x[0], x[1], x[2]}, tb = 0.f;
         float xprev[3] = {x[0], x[1], x[2]}; // end of the piece before (start of the step at first)
-        int msub = 1;
-        if (nboxes > 0 && live) {
-            const float sp = sqrtf(dot3f(v, v)) * dt, piece = 0.5f * r;
-            if (sp > piece) msub = (int)fminf(ceilf(sp / piece), (float)SPH_MAX_SUBSTEPS);
-        }
-        int mw = msub;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) mw = max(mw, __shfl_xor(mw, d, 64));
-        mw = __builtin_amdgcn_readfirstlane(mw);
+        // pieces: the rest of the step is cut into ceil(|v| rest / (r/2)) equal parts and the first
+        // is taken; after every piece the cut is made afresh with the velocity the particle then has
+        // (a moving box can hand a slow particle a large one in the middle of a step)
+        const float piece = 0.5f * r;
+        float tnow = 0.f;
+        auto next_time = [&](int npieces) -> float {
+            float ts = dt;
+            if (npieces < SPH_MAX_SUBSTEPS - 1) {
+                const float rest = dt - tnow, sp = sqrtf(dot3f(v, v)) * rest;
+                if (sp > piece) { // (never more parts than pieces are left: then they are longer)
+                    const float mm = fminf(ceilf(sp / piece), (float)(SPH_MAX_SUBSTEPS - npieces));
+                    if (mm > 1.f) ts = tnow + rest / mm;
+                }
+            }
+            return ts;
+        };
+        bool several = nboxes > 0 && live && next_time(0) < dt; // more than one piece to take
+        int mw = __any(several) ? 2 : 1;
 #pragma unroll
         for (int a = 0; a < 3; a++) x[a] = xb[a] + v[a] * dt;
         // Broadphase: the particles of a wave are neighbours in the sorted order (a few cells), so
@@ -318,9 +327,10 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
             }
             if (!any) mw = 0;
         }
-        for (int s = 1; s <= mw; s++) {
-        const bool act = live && s <= msub;
-        const float ts = s == msub ? dt : dt * ((float)s / (float)msub);
+        for (int npieces = 0; mw > 0; npieces++) {
+        const bool act = live && tnow < dt;
+        if (!__any(act)) break;
+        const float ts = next_time(npieces);
         const float xs[3] = {xprev[0], xprev[1], xprev[2]}; // where the piece starts: outside every static box
         if (act) {
             const float tau = ts - tb;
@@ -486,6 +496,7 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
         if (act) {
 #pragma unroll
             for (int a = 0; a < 3; a++) xprev[a] = x[a];
+            tnow = ts;
         }
         }
     }

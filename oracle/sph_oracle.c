@@ -528,7 +528,7 @@ static inline void cross3(const float *a, const float *b, float *o)
 
 /* particles: x += v*dt, then sphere(radius params[4i]) vs every box in order.
  * Swept: a particle that moves farther than half its radius in the step takes the step in
- * m = ceil(|v| dt / (r/2)) equal pieces (at most ORC_MAX_SUBSTEPS) and is tested against the boxes
+ * pieces no longer than r/2 (at most ORC_MAX_SUBSTEPS of them) and is tested against the boxes
  * after each, so that it is never carried through a box that is at least as thick as its radius:
  * a piece of r/2 takes a centre that is outside the box (even one that starts ON a face, as the
  * bottom layer of the demo lattice does) less than half the thickness deep, where the nearest face
@@ -536,7 +536,7 @@ static inline void cross3(const float *a, const float *b, float *o)
  * xb + v (t_s - tb), (xb, tb) = where and when the particle last touched a box (the start of the
  * step at first): without a contact the end position is x + v dt exactly as without pieces.
  * body_impulse: K x 6 floats (linear impulse, angular impulse about the centre), accumulated. */
-#define ORC_MAX_SUBSTEPS 64
+#define ORC_MAX_SUBSTEPS 256
 static int box_dynamic_(const OrcBox *bx)
 {
     return bx->invMass != 0.0f || bx->invInertia[0] != 0.0f || bx->invInertia[1] != 0.0f ||
@@ -556,13 +556,19 @@ ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMas
             v[a] = vel[3 * i + a];
             xb[a] = x[a] = pos[3 * i + a];
         }
-        int msub = 1;
-        if (nboxes > 0) {
-            float sp = sqrtf(dot3(v, v)) * dt, piece = 0.5f * r;
-            if (sp > piece) msub = (int)fminf(ceilf(sp / piece), (float)ORC_MAX_SUBSTEPS);
+        /* pieces: the rest of the step is cut into ceil(|v| rest / (r/2)) equal parts and the first
+         * is taken; after every piece the cut is made afresh with the velocity the particle then
+         * has (a moving box can hand a slow particle a large one in the middle of a step) */
+        float tnow = 0.0f;
+        for (int npieces = 0; tnow < dt; npieces++) {
+        float ts = dt;
+        if (nboxes > 0 && npieces < ORC_MAX_SUBSTEPS - 1) {
+            float rest = dt - tnow, sp = sqrtf(dot3(v, v)) * rest, piece = 0.5f * r;
+            if (sp > piece) { /* (never more parts than pieces are left: then they are longer) */
+                float m = fminf(ceilf(sp / piece), (float)(ORC_MAX_SUBSTEPS - npieces));
+                if (m > 1.0f) ts = tnow + rest / m;
+            }
         }
-        for (int s = 1; s <= msub; s++) {
-        const float ts = s == msub ? dt : dt * ((float)s / (float)msub);
         const float tau = ts - tb;
         int touched = 0;
         const float xs[3] = {x[0], x[1], x[2]}; /* where the piece starts: outside every static box */
@@ -658,6 +664,7 @@ ORC_API void orc_integrate_particles(float *pos, float *vel, const float *invMas
             for (int a = 0; a < 3; a++) xb[a] = x[a];
             tb = ts;
         }
+        tnow = ts;
         }
         for (int a = 0; a < 3; a++) {
             pos[3 * i + a] = x[a];
