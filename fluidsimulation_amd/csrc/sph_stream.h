@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_reorder(
     if (s < n) {
         pm = posmIn[c];
         vq = velqIn[c];
-        mt = matIn[c];
+        if (matIn) mt = matIn[c]; // (null: one material, both index buffers hold zeros)
     }
     ids[threadIdx.x] = id;
     __syncthreads();
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_reorder(
     const int dst = cell.x + rank;
     posmOut[dst] = pm;
     velqOut[dst] = vq;
-    matOut[dst] = mt;
+    if (matIn) matOut[dst] = mt;
     oidOut[dst] = id;
 }
 
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
     if (live) {
         pv = posm[i];
         vv = velq[i];
-        m = mats[mat[i]];
+        if (mat) m = mats[mat[i]]; // (null: one material)
         if (slabFlags) owned = (slabFlags[i] & 0x80000000u) == 0;
     }
     float x[3] = {pv.x, pv.y, pv.z}, v[3] = {vv.x, vv.y, vv.z};

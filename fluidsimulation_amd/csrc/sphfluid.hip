@@ -118,6 +118,7 @@ struct SphCtx {
     std::unordered_map<MatKey, uint32_t, MatKeyHash> matIndex;
     std::vector<uint32_t> hostMatIdx;
     bool matUniform = false; // every particle of the last upload carries material 0
+    bool matAllZero = false; // ... and both material-index buffers hold zeros: reorder and integrate leave them alone
     // SphConfig.pinHostArrays: caller arrays registered with the driver (page-locked) on first
     // use and kept, so that the per-frame copies of the host round trips run as DMA at PCIe rate
     bool pinHost = false;
@@ -1046,6 +1047,13 @@ int sph_upload(SphCtx *c, const float *pos, const float *vel, const float *invMa
                                                             c->dmats.p, N, c->posm[0].p,
                                                             c->velq[0].p, c->mat[0].p, c->oid[0].p);
     HIPCHK(c, hipGetLastError());
+    // one material (the usual scene): the index array is all zeros and need not travel with the
+    // particles -- 8 of the reorder pass's 96 bytes per particle, 4 of the integrate pass's 72
+    c->matAllZero = false;
+    if (c->matUniform) {
+        HIPCHK(c, hipMemsetAsync(c->mat[1].p, 0, (size_t)4 * N, c->stream));
+        c->matAllZero = true;
+    }
     c->haveKeys = c->haveSort = c->haveTable = c->ordered = false;
     c->haveDensity = c->haveForce = false;
     if (c->gridExplicit) {
@@ -1177,8 +1185,9 @@ int sph_reorder(SphCtx *c)
     StageTimer t(c, SPH_T_REORDER);
     const int N = c->n, cur = c->cur, nxt = cur ^ 1;
     k_reorder<<<blocks_for(N, 256), 256, 0, c->stream>>>(
-        c->sortedVals, c->sortedKeys, c->table.p, N, c->posm[cur].p, c->velq[cur].p, c->mat[cur].p,
-        c->oid[cur].p, c->posm[nxt].p, c->velq[nxt].p, c->mat[nxt].p, c->oid[nxt].p);
+        c->sortedVals, c->sortedKeys, c->table.p, N, c->posm[cur].p, c->velq[cur].p,
+        c->matAllZero ? nullptr : c->mat[cur].p, c->oid[cur].p, c->posm[nxt].p, c->velq[nxt].p,
+        c->mat[nxt].p, c->oid[nxt].p);
     HIPCHK(c, hipGetLastError());
     c->cur = nxt;
     c->ordered = true;
@@ -1352,7 +1361,8 @@ static int launch_apply_integrate(SphCtx *c, const SphParams *p, bool apply, boo
     const int nb = blocks_for(N, 256);
 #define LAUNCH_AI(A, I)                                                                          \
     k_apply_integrate<A, I><<<nb, 256, 0, c->stream>>>(                                          \
-        c->posm[cur].p, c->velq[cur].p, c->force.p, c->rho.p, c->mat[cur].p, c->dmats.p, N,      \
+        c->posm[cur].p, c->velq[cur].p, c->force.p, c->rho.p,                                    \
+        c->matAllZero ? nullptr : c->mat[cur].p, c->dmats.p, N,                                  \
         p->dt, c->devBoxes.p, c->nboxes, p->particleRestitution, c->bodyImpulse.p,               \
         c->boxAabb.p, c->chunkAabb.p,                                                            \
         c->slab ? c->oid[cur].p : nullptr, nextKeys ? c->keysA.p : nullptr, c->grid)
@@ -1822,6 +1832,7 @@ int sph_seed_volume(SphCtx *c, const float localToWorld[12], const float boundsM
     if (c->slab) return fail(c, SPH_E_INVALID, "sph_seed_volume is not available in slab mode");
     if (!(radius > 0.f) || !(invMass > 0.f) || !(gridSize > 0.f) || !std::isfinite(gridSize))
         return fail(c, SPH_E_INVALID, "radius, invMass and gridSize must be positive");
+    c->matAllZero = false; // (seeded particles carry their own material index)
     SeedDesc d;
     long long count = 1;
     int num[3];
@@ -1897,6 +1908,7 @@ int sph_slab_upload(SphCtx *c, const float *pos, const float *vel, const uint32_
     if (!c) return SPH_E_INVALID;
     if (N < 0 || (N > 0 && (!pos || !vel || !materialIndex || !ids)) || !materials || M <= 0)
         return fail(c, SPH_E_INVALID, "sph_slab_upload: bad arrays");
+    c->matAllZero = false;
     if (capacity < std::max(N, 1)) return fail(c, SPH_E_INVALID, "capacity below N");
     if (!(gridSize > 0.f) || !std::isfinite(gridSize))
         return fail(c, SPH_E_INVALID, "gridSize must be positive and finite");
