@@ -330,6 +330,10 @@ def main():
                     c2.step_inplace(p, hp, hv, sc.inv_mass, sc.params)
                 dt_ = (time.perf_counter() - t1) / frames
                 st = c2.pin_stats()
+                if st["failed"]:
+                    import resource
+                    st["reason"] = c2.lib.sph_last_error(c2.h).decode()
+                    st["rlimit_memlock"] = resource.getrlimit(resource.RLIMIT_MEMLOCK)[0]
                 c2.unpin_host()          # hp / hv go away with this frame
                 return dt_, st
             ctx.close()

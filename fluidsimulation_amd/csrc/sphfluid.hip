@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -79,6 +80,87 @@ static __device__ __align__(256) unsigned char scratch[sizeof(SortScratch)];
 static SortScratch *g_scratchPtr[SPH_MAX_DEVICES]; // per device; written under g_scratchLock
 static std::mutex g_scratchLock;
 
+struct Stage {
+    static constexpr size_t CHUNK = 16u << 20;
+    static constexpr int SLOTS = 3;
+    char *buf[SLOTS] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr};
+    bool busy[SLOTS] = {false, false, false}; // an H2D copy out of the slot may still be running
+    // worker threads: copy part i of the current job
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cvWork, cvDone;
+    char *dst = nullptr;
+    const char *src = nullptr;
+    size_t len = 0;
+    int parts = 0, taken = 0, done = 0;
+    uint64_t gen = 0;
+    bool quit = false;
+
+    static void copy_part(char *d, const char *s0, size_t n, int part, int parts)
+    {
+        const size_t per = ((n + parts - 1) / parts + 63) & ~(size_t)63;
+        const size_t lo = std::min(n, per * (size_t)part), hi = std::min(n, lo + per);
+        if (hi > lo) std::memcpy(d + lo, s0 + lo, hi - lo);
+    }
+    void worker()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cvWork.wait(lk, [&] { return quit || (gen != seen && taken < parts); });
+            if (quit) return;
+            while (taken < parts) {
+                const int part = taken++;
+                char *d = dst;
+                const char *s0 = src;
+                const size_t n = len;
+                const int np = parts;
+                lk.unlock();
+                copy_part(d, s0, n, part, np);
+                lk.lock();
+                if (++done == parts) cvDone.notify_all();
+            }
+            seen = gen;
+        }
+    }
+    // memcpy by the calling thread and the workers together
+    void copy(char *d, const char *s0, size_t n)
+    {
+        if (n < (2u << 20) || th.empty()) {
+            std::memcpy(d, s0, n);
+            return;
+        }
+        std::unique_lock<std::mutex> lk(m);
+        dst = d; src = s0; len = n;
+        parts = (int)th.size() + 1;
+        taken = done = 0;
+        gen++;
+        cvWork.notify_all();
+        while (taken < parts) {
+            const int part = taken++;
+            lk.unlock();
+            copy_part(d, s0, n, part, parts);
+            lk.lock();
+            ++done;
+        }
+        cvDone.wait(lk, [&] { return done == parts; });
+    }
+    ~Stage()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cvWork.notify_all();
+        for (auto &t : th) t.join();
+        for (int i = 0; i < SLOTS; i++) {
+            if (buf[i]) (void)hipHostFree(buf[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
+    }
+};
+
 struct SphCtx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -125,6 +207,11 @@ struct SphCtx {
     struct Pinned { const void *p; size_t bytes /* registered, 0 = registration failed */, asked; };
     std::vector<Pinned> pinned;
     int pinOk = 0, pinFailed = 0;
+    // Staged host copies (arrays that are not registered): a ring of pinned chunks owned by the
+    // library, filled / emptied by a few host threads while the DMA of the chunk before runs
+    Stage *stage = nullptr;
+    bool stageFailed = false;
+    std::string pinErr; // text of the last failed registration
 
     // grid
     GridDesc grid{};
@@ -293,6 +380,101 @@ int collect_timings(SphCtx *c)
         c->freeEvents.push_back(ep.b);
     }
     c->pending.clear();
+    return SPH_OK;
+}
+
+// ---- staged host <-> device copies ----------------------------------------------------------
+// The span FluidSPHByGPUSystem.cs:227-233,249-252 (SetData / readback of the packed arrays) is a
+// copy of caller-owned, pageable memory.  Registering the caller's arrays (SphConfig.pinHostArrays)
+// is the zero-copy way, but a driver may refuse it (this pool's boxes do: hipHostRegister returns
+// "invalid argument" for any pointer), and the runtime's own pageable path is a single-threaded
+// copy through one bounce buffer (17-24 GB/s up, 10 GB/s down here).  So large copies of
+// unregistered arrays go through a ring of pinned chunks of the library's own: a few host threads
+// fill (or empty) one chunk while the DMA engine moves the one before.
+// the ring, made on first use; nullptr when it cannot be had (the copies then go the plain way)
+Stage *stage_of(SphCtx *c)
+{
+    if (c->stage) return c->stage;
+    if (c->stageFailed) return nullptr;
+    Stage *st = new (std::nothrow) Stage();
+    bool ok = st != nullptr;
+    for (int i = 0; ok && i < Stage::SLOTS; i++)
+        ok = hipHostMalloc((void **)&st->buf[i], Stage::CHUNK, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&st->ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        delete st;
+        c->stageFailed = true;
+        return nullptr;
+    }
+    int nt = 4;
+    if (const char *e = getenv("SPHFLUID_STAGE_THREADS")) nt = atoi(e);
+    nt = std::max(1, std::min(nt, (int)std::max(1u, std::thread::hardware_concurrency())));
+    for (int i = 1; i < nt; i++) st->th.emplace_back([st] { st->worker(); });
+    c->stage = st;
+    return st;
+}
+
+bool is_registered(const SphCtx *c, const void *p)
+{
+    for (const auto &e : c->pinned)
+        if (e.p == p && e.bytes) return true;
+    return false;
+}
+
+// host -> device, asynchronous on the context's stream as far as the device is concerned; the host
+// array has been read in full when this returns
+int copy_h2d(SphCtx *c, void *dstDev, const void *srcHost, size_t bytes)
+{
+    Stage *st = (bytes >= (8u << 20) && !is_registered(c, srcHost)) ? stage_of(c) : nullptr;
+    if (!st) {
+        HIPCHK(c, hipMemcpyAsync(dstDev, srcHost, bytes, hipMemcpyHostToDevice, c->stream));
+        return SPH_OK;
+    }
+    int k = 0;
+    for (size_t off = 0; off < bytes; off += Stage::CHUNK, k++) {
+        const int slot = k % Stage::SLOTS;
+        const size_t n = std::min(Stage::CHUNK, bytes - off);
+        if (st->busy[slot]) HIPCHK(c, hipEventSynchronize(st->ev[slot]));
+        st->copy(st->buf[slot], (const char *)srcHost + off, n);
+        HIPCHK(c, hipMemcpyAsync((char *)dstDev + off, st->buf[slot], n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(st->ev[slot], c->stream));
+        st->busy[slot] = true;
+    }
+    return SPH_OK;
+}
+
+// device -> host; the host array is complete when this returns (it synchronises)
+int copy_d2h(SphCtx *c, void *dstHost, const void *srcDev, size_t bytes)
+{
+    Stage *st = (bytes >= (8u << 20) && !is_registered(c, dstHost)) ? stage_of(c) : nullptr;
+    if (!st) {
+        HIPCHK(c, hipMemcpyAsync(dstHost, srcDev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return SPH_OK;
+    }
+    const int nchunks = (int)((bytes + Stage::CHUNK - 1) / Stage::CHUNK);
+    auto issue = [&](int k) -> hipError_t {
+        const int slot = k % Stage::SLOTS;
+        const size_t off = (size_t)k * Stage::CHUNK, n = std::min(Stage::CHUNK, bytes - off);
+        if (st->busy[slot]) { // (an upload out of the slot)
+            const hipError_t e = hipEventSynchronize(st->ev[slot]);
+            if (e != hipSuccess) return e;
+            st->busy[slot] = false;
+        }
+        hipError_t e = hipMemcpyAsync(st->buf[slot], (const char *)srcDev + off, n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(st->ev[slot], c->stream);
+        return e;
+    };
+    // two chunks in flight while the third is being emptied
+    for (int k = 0; k < std::min(nchunks, Stage::SLOTS - 1); k++) HIPCHK(c, issue(k));
+    for (int k = 0; k < nchunks; k++) {
+        const int slot = k % Stage::SLOTS;
+        const size_t off = (size_t)k * Stage::CHUNK, n = std::min(Stage::CHUNK, bytes - off);
+        HIPCHK(c, hipEventSynchronize(st->ev[slot]));
+        if (k + Stage::SLOTS - 1 < nchunks) HIPCHK(c, issue(k + Stage::SLOTS - 1));
+        st->copy((char *)dstHost + off, st->buf[slot], n);
+    }
     return SPH_OK;
 }
 
@@ -782,6 +964,7 @@ int sph_destroy(SphCtx *c)
     (void)sph_slab_comm_destroy(c);
     for (auto &e : c->pinned)
         if (e.bytes) (void)hipHostUnregister(const_cast<void *>(e.p));
+    delete c->stage; // (after the stream has drained: joins its threads, frees the pinned ring)
     (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->evTable) (void)hipEventDestroy(c->evTable);
@@ -957,12 +1140,18 @@ static void pin_host(SphCtx *c, const void *p, size_t bytes)
 {
     if (!c->pinHost || !p || bytes < (1u << 20)) return;
     auto reg = [&](size_t n) -> size_t {
-        if (hipHostRegister(const_cast<void *>(p), n, hipHostRegisterDefault) == hipSuccess) {
+        const hipError_t e = hipHostRegister(const_cast<void *>(p), n, hipHostRegisterDefault);
+        if (e == hipSuccess) {
             c->pinOk++;
             return n;
         }
         (void)hipGetLastError();
         c->pinFailed++;
+        // not an error of the call in progress, but the text is kept where the host can read it
+        char buf[256];
+        snprintf(buf, sizeof(buf), "hipHostRegister(%zu bytes) failed: %s -- the array goes through the "
+                                   "library's pinned staging ring instead", n, hipGetErrorString(e));
+        c->pinErr = buf;
         return 0;
     };
     for (auto &e : c->pinned)
@@ -1010,6 +1199,7 @@ int sph_pin_stats(SphCtx *c, int32_t stats[3])
     stats[0] = live;
     stats[1] = c->pinOk;
     stats[2] = c->pinFailed;
+    if (c->pinFailed && !c->pinErr.empty()) c->err = c->pinErr; // (sph_last_error gives the reason)
     return SPH_OK;
 }
 
@@ -1036,8 +1226,8 @@ int sph_upload(SphCtx *c, const float *pos, const float *vel, const float *invMa
     c->nOwned = c->nGhost = c->nDead = 0;
     pin_host(c, pos, (size_t)12 * N);
     pin_host(c, vel, (size_t)12 * N);
-    HIPCHK(c, hipMemcpyAsync(c->io3a.p, pos, (size_t)12 * N, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->io3b.p, vel, (size_t)12 * N, hipMemcpyHostToDevice, c->stream));
+    if ((rc = copy_h2d(c, c->io3a.p, pos, (size_t)12 * N))) return rc;
+    if ((rc = copy_h2d(c, c->io3b.p, vel, (size_t)12 * N))) return rc;
     if (c->matUniform)
         HIPCHK(c, hipMemsetAsync(c->ioU.p, 0, (size_t)4 * N, c->stream));
     else
@@ -1082,18 +1272,16 @@ int sph_download(SphCtx *c, float *pos_out, float *vel_out)
     const int cur = c->cur;
     pin_host(c, pos_out, (size_t)12 * N);
     pin_host(c, vel_out, (size_t)12 * N);
-    if (pos_out) {
+    // (both unpack kernels first: the second runs while the first array crosses the link)
+    if (pos_out)
         k_unpack3<<<blocks_for(N, 256), 256, 0, c->stream>>>(c->posm[cur].p, c->oid[cur].p, N,
                                                              c->io3a.p);
-        HIPCHK(c, hipMemcpyAsync(pos_out, c->io3a.p, (size_t)12 * N, hipMemcpyDeviceToHost,
-                                 c->stream));
-    }
-    if (vel_out) {
+    if (vel_out)
         k_unpack3<<<blocks_for(N, 256), 256, 0, c->stream>>>(c->velq[cur].p, c->oid[cur].p, N,
                                                              c->io3b.p);
-        HIPCHK(c, hipMemcpyAsync(vel_out, c->io3b.p, (size_t)12 * N, hipMemcpyDeviceToHost,
-                                 c->stream));
-    }
+    HIPCHK(c, hipGetLastError());
+    if (pos_out && (rc = copy_d2h(c, pos_out, c->io3a.p, (size_t)12 * N))) return rc;
+    if (vel_out && (rc = copy_d2h(c, vel_out, c->io3b.p, (size_t)12 * N))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SPH_OK;
 }
@@ -1576,9 +1764,7 @@ static int read_ecs(SphCtx *c, int32_t buffer, void *out)
     }
     HIPCHK(c, hipGetLastError());
     pin_host(c, out, bytes);
-    HIPCHK(c, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SPH_OK;
+    return copy_d2h(c, out, src, bytes);
 }
 
 // SPH_BUF_MASK_COUNTS / SPH_BUF_MASK_IDSUMS: the production density pass's hit masks, walked as the

@@ -93,7 +93,11 @@ typedef struct SphConfig {
     int32_t enableTimings;   /* HIP events per stage (sph_get_timings): 1 every stage (about 1.4 % of a
                                 C3 step: each pair of events puts a bubble between two kernels), 2 the two
                                 neighbour kernels only */
-    int32_t pinHostArrays;   /* !=0: caller arrays of sph_upload / sph_download / sph_step* are
+    int32_t pinHostArrays;   /* Host copies: large arrays (>= 8 MB) that are not registered go through a
+                                ring of pinned 16 MB chunks of the library's own, filled / emptied by a few
+                                host threads (SPHFLUID_STAGE_THREADS, default 4) while the DMA of the chunk
+                                before runs.
+                                !=0: caller arrays of sph_upload / sph_download / sph_step* are
                                 registered with the driver on first use (hipHostRegister) and stay
                                 registered until sph_unpin_host / sph_destroy: use it when the same
                                 arrays come back every frame (persistent NativeArrays), and call
@@ -203,7 +207,8 @@ SPH_API int sph_download(SphCtx *ctx, float *pos_out /* N*3 */, float *vel_out /
  * caller's arrays themselves are registered).  sph_unpin_host releases the registration of one
  * array (array == NULL: of all): call it BEFORE freeing or reallocating an array the context has
  * seen.  sph_pin_stats: stats[0] = arrays registered now, [1] = registrations that succeeded,
- * [2] = that failed (those arrays are copied from pageable memory), since sph_create. */
+ * [2] = that failed (those arrays are copied from pageable memory), since sph_create; after a
+ * failure sph_last_error holds the driver's reason for the last one. */
 SPH_API int sph_unpin_host(SphCtx *ctx, const void *array);
 SPH_API int sph_pin_stats(SphCtx *ctx, int32_t stats[3]);
 /* FluidInitializeSystem.CreateParticles (FluidInitializeSystem.cs:63-92) on the device, so that a
