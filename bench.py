@@ -298,9 +298,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, a.config, n) if world == 1 else None,
-                         "limiter": "fp32 VALU issue, not HBM: SQ_INSTS_VALU x 2.6 cycles (measured "
-                                    "issue rate, profiles/r2_microbench_valu.txt) is ~70 % of the "
-                                    "neighbour kernels' SIMD cycles (profiles/r2_*)",
+                         "limiter": "fp32 VALU issue, not HBM: SQ_INSTS_VALU x 2.6 cycles (the measured "
+                                    "issue rate, profiles/r2_microbench_valu.txt) is 0.88 of the density "
+                                    "kernel's SIMD cycles and 0.81 of the force kernel's "
+                                    "(profiles/r3_b_C3_rocprofv3_summary.txt); `traffic` is that profile's "
+                                    "PMC figure (2 x FETCH_SIZE + WRITE_SIZE), not measured in this run",
                          "alg_bytes_per_particle": alg[dom],
                          "avg_launch_ms": stage_ms[dom]},
             # the two neighbour kernels take nearly the same time: both fractions, whichever leads
