@@ -166,6 +166,7 @@ struct NbArgs {
     int gcellCap;
     uint4 *pool;              // plans
     uint32_t poolCap;         // in 16-byte units
+    uint32_t *gmaskOff;       // per cell of gcellList: pool offset of its hit masks (0xffffffff: none)
 };
 
 __device__ __forceinline__ int wrapi(int c, int g) { return c < 0 ? c + g : (c >= g ? c - g : c); }
@@ -822,7 +823,10 @@ __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_
                         if (plan_block<1, 1, 1>(sh, A, tileCur, bx, by, z, la PT_ARG)) continue;
                         if (threadIdx.x == 0 && sh.h.fc[tile_halo_index(bx + 1, by + 1, z + 1)] > 0) {
                             const uint32_t idx = atomicAdd(&A.ctl[NB_CTL_GCELLS], 1u);
-                            if (idx < (uint32_t)A.gcellCap) A.gcellList[idx] = make_int2(tileCur, bx | (by << 8) | (z << 16));
+                            if (idx < (uint32_t)A.gcellCap) {
+                                A.gcellList[idx] = make_int2(tileCur, bx | (by << 8) | (z << 16));
+                                A.gmaskOff[idx] = 0xffffffffu;
+                            }
                             else atomicOr(&A.ctl[NB_CTL_ERROR], 2u);
                         }
                     }
@@ -1119,25 +1123,106 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
 
 // A cell whose 27-cell neighbourhood overflows the LDS image (the bottom of a deep tank while the
 // column lands: hundreds of particles per cell).  The reference's hash chains have no occupancy
-// limit (FluidSPHByCPUSystem.cs:69-75); here the cell's targets stay in registers -- 32 per wave,
-// two candidate slices each -- and the candidates of its 27 cells, fluid then boundary per cell,
-// are streamed through the same image in chunks by LDS-DMA, every wave walking each chunk for its
-// own targets.  (Round 2 read every candidate from global memory per lane: 14-19 ms per step on
-// C3 while the column lands.)  No hit masks: the force pass walks every candidate here too.
+// limit (FluidSPHByCPUSystem.cs:69-75); here the cell's targets stay in registers -- a group of at
+// most 32 per wave, 64 / group candidate slices each -- and the candidates of its 27 cells are
+// streamed through the same image by LDS-DMA, every wave walking each image for its own targets.  (Round 2 read every
+// candidate from global memory per lane: 14-19 ms per step on C3 while the column lands.)
+//
+// The candidates are ONE stream: the 27 fluid ranges, then the 27 boundary ranges, back to back
+// (sh.plan holds the prefix table behind the halo table); an image is NB_GCHUNK consecutive stream
+// positions, whatever ranges they come from, so a neighbourhood of 1500 candidates is two images
+// and two barriers, not 54.  Slot q of an image is its records q S .. q S + S - 1, one per slice.
+//
+// Hit masks as in the planned path: the density pass stores, per group of targets (= one wave and
+// pass), lane and 32 slots, one word of hit bits, image after image, in pool space it takes
+// with one atomic per group (NbArgs::gmaskOff keeps the offset; no space left: no masks, the force
+// pass walks every candidate of that group).  The force pass holds the words of 128 slots in four
+// registers and walks their set bits; the next four are in flight meanwhile.
+#define NB_GCHUNK (NB_CAP - 64) // candidate records per image; 64 FAR records follow them
+#define NB_GNOMASK 0xffffffffu
+#ifndef NB_GSCATTER
+#define NB_GSCATTER 1
+#endif
+#ifndef NB_GGROUPMIN
+#define NB_GGROUPMIN NB_MAXWAVES
+#endif
 template <bool FORCE, bool COUNT>
 __device__ void process_cell_chunked(NbShared<FORCE, COUNT> &sh, const HaloTab &ht, const NbArgs &A,
-                                     int lx, int ly, int lz)
+                                     uint32_t gi, int lx, int ly, int lz)
 {
     constexpr int NT = FORCE ? NB_FTHREADS : NB_DTHREADS, NB_WAVES = NT / 64;
-    constexpr int TPW = 32;            // targets per wave and pass
-    constexpr int CHUNK = NB_CAP - 64; // candidate records per chunk; 64 FAR records follow them
+    constexpr int CHUNK = NB_GCHUNK;
+    constexpr bool MASKS_OUT = !FORCE && !COUNT, MASKS_IN = FORCE && !COUNT;
+    static_assert(sizeof(HaloTab) + 128 * sizeof(int) <= NB_PLANMAX, "range table behind the halo table");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int f = tile_halo_index(lx + 1, ly + 1, lz + 1);
     const int ncell = uniform_i(ht.fc[f]), cstart = uniform_i(ht.fs[f]);
     float4 *recP = sh.recP, *recV = sh.recV;
-    for (int tb = 0; tb < ncell; tb += NB_WAVES * TPW) { // (workgroup-uniform)
-        const int t0 = tb + w * TPW;
-        const int T = max(0, min(TPW, ncell - t0)); // wave-uniform; 0: the wave only helps to copy
+    // groups of at most 32 targets, at least as many as the force kernel has waves (a cell of 55
+    // targets keeps eight waves busy with seven targets and nine slices each); the same groups in
+    // both passes, whatever their workgroup size: the hit masks are per group
+    const int ngroups0 = max(NB_GGROUPMIN, (ncell + 31) >> 5);
+    const int per = (ncell + ngroups0 - 1) / ngroups0, ngroups = (ncell + per - 1) / per;
+    const int sfull = slices_for(per); // (a last, smaller group has more slices and fewer slots)
+    // mask words of one group for a stream of sl records: per image, one word per 32 slots
+    auto group_words = [&](int sl) {
+        const int full = sl / CHUNK, last = sl - full * CHUNK;
+        return full * ((div_small(CHUNK + sfull - 1, sfull) + 31) >> 5) + ((div_small(last + sfull - 1, sfull) + 31) >> 5);
+    };
+    // the stream: rpre[r] = stream position of range r (r = 54: the end, then INT_MAX), rsrc[r] =
+    // its first record in posm (r < 27) or bposm; rsrc[60] = pool offset of the cell's hit masks
+    int *rpre = (int *)(sh.plan + sizeof(HaloTab)), *rsrc = rpre + 64;
+    if (w == 0) {
+        int n = 0, s = 0;
+        if (lane < 54) {
+            const int c27 = lane < 27 ? lane : lane - 27;
+            const int h = f + ((c27 / 9) - 1) * (NB_HX * NB_HY) + (((c27 / 3) % 3) - 1) * NB_HX + (c27 % 3) - 1;
+            s = lane < 27 ? ht.fs[h] : ht.bs[h]; // fluid (index != j, :152), then boundary (:184-189)
+            n = lane < 27 ? ht.fc[h] : ht.bc[h];
+        }
+        const int incl = wave_incl_scan(n);
+        rpre[lane] = lane <= 54 ? incl - n : 0x7fffffff;
+        rsrc[lane] = s;
+        // One atomic per cell takes the pool space of all its groups (one per group -- a million
+        // returning atomics on one word per launch -- took 6 ms of the density pass).  No space
+        // left: no masks, the force pass walks every candidate of the cell.
+        uint32_t off = NB_GNOMASK;
+        if (MASKS_OUT) {
+            const int sl = ((__builtin_amdgcn_readlane(incl, 63) + 3) >> 2) * 4;
+            const uint32_t units = (uint32_t)(ngroups * group_words(sl)) * 16u;
+            if (lane == 0) {
+                off = atomicAdd(&A.ctl[NB_CTL_POOL], units);
+                // (the counter may run past the capacity: the sum stays far below 2^32)
+                if (off > A.poolCap || units > A.poolCap - off) off = NB_GNOMASK;
+                A.gmaskOff[gi] = off;
+            }
+        } else if (MASKS_IN) {
+            if (lane == 0 && A.useMasks) off = A.gmaskOff[gi];
+        }
+        if (lane == 0) rsrc[60] = (int)off;
+    }
+    lds_barrier();
+    const int rtot = uniform_i(rpre[54]);
+    // The stream is walked in a scattered order: quad (4 records, 64 bytes) q of the images is quad
+    // q K mod Q of the stream, K next to Q / golden ratio and coprime to Q, so that any run of
+    // slots holds records of all 27 cells in proportion and every target meets its hits at an
+    // even rate -- the mask walk of the force pass lasts as long as its busiest lane.  (The
+    // counting variants keep the stream's own order: they need the target's own place in it.)
+    const int nquads = (rtot + 3) >> 2, slen = nquads * 4;
+    int stride = 1;
+    if (!COUNT && NB_GSCATTER) {
+        stride = max(1, (int)((float)nquads * 0.6180339887f));
+        for (;; stride++) {
+            int a = stride, b = nquads;
+            while (b) { const int t = a % b; a = b; b = t; }
+            if (a == 1) break;
+        }
+    }
+    const int selfBase = uniform_i(rpre[13]) - cstart; // stream position of sorted index ti: ti + selfBase
+    const uint32_t maskBase = (uint32_t)uniform_i(rsrc[60]), groupUnits = (uint32_t)group_words(slen) * 16u;
+    for (int g0 = 0; g0 < ngroups; g0 += NB_WAVES) { // (workgroup-uniform)
+        const int grp = g0 + w, t0 = grp * per;
+        const int T = max(0, min(per, ncell - t0)); // wave-uniform; 0: the wave only helps to copy
         const int S = T > 0 ? slices_for(T) : 64;
         int u, slice;
         split_lane(lane, S, u, slice);
@@ -1161,43 +1246,94 @@ __device__ void process_cell_chunked(NbShared<FORCE, COUNT> &sh, const HaloTab &
             ps.t.negInvH2 = tkv;
             ps.t.h2 = thr;
         }
-        for (int c27 = 0; c27 < 27; c27++) {
-            const int h = f + ((c27 / 9) - 1) * (NB_HX * NB_HY) + (((c27 / 3) % 3) - 1) * NB_HX +
-                          (c27 % 3) - 1;
-            for (int kind = 0; kind < 2; kind++) { // fluid (index != j, :152), then boundary (:184-189)
-                const bool fluid = kind == 0;
-                const int s0 = uniform_i(fluid ? ht.fs[h] : ht.bs[h]);
-                const int e0 = s0 + uniform_i(fluid ? ht.fc[h] : ht.bc[h]);
-                const float4 *srcP = fluid ? A.posm : A.bposm;
-                for (int c0 = s0; c0 < e0; c0 += CHUNK) {
-                    const int cnt = min(CHUNK, e0 - c0);
-                    lds_barrier(); // every wave is done with the chunk before
-                    for (int p0 = w * 64; p0 < cnt + 64; p0 += NT) { // wave-uniform
-                        const int k = p0 + lane;
-                        if (k < cnt) {
-                            __builtin_amdgcn_global_load_lds((gptr_t)(srcP + c0 + k), (lptr_t)(recP + p0), 16, 0, 0);
-                            if (FORCE) {
-                                const float4 *gv = fluid ? (const float4 *)A.velq + c0 + k : A.zeros;
-                                __builtin_amdgcn_global_load_lds((gptr_t)gv, (lptr_t)(recV + p0), 16, 0, 0);
-                            }
-                        } else if (k < cnt + 64) { // what the last slot's slices past the end read
-                            recP[k] = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f);
-                            if (FORCE) recV[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
+        // the group's mask words: one per image and 32 slots (wave-uniform count)
+        uint32_t *maskW = nullptr; // + 64 per word
+        if ((MASKS_OUT || MASKS_IN) && T > 0 && maskBase != NB_GNOMASK)
+            maskW = (uint32_t *)(A.pool + maskBase + (uint32_t)grp * groupUnits) + lane;
+        const bool walkMasks = MASKS_IN && maskW != nullptr; // wave-uniform
+        const int self = ti + selfBase;                      // the target's own stream position
+        for (int i0 = 0; i0 < slen; i0 += CHUNK) {
+            const int cnt = min(CHUNK, slen - i0);
+            lds_barrier(); // every wave is done with the image before
+            for (int p0 = w * 64; p0 < cnt + 64; p0 += NT) { // wave-uniform
+                const int k = p0 + lane;
+                const int at = i0 + k; // place in the images -> place in the stream
+                const int pos = (int)((uint32_t)((at >> 2) * stride) % (uint32_t)nquads) * 4 + (at & 3);
+                if (k < cnt && pos < rtot) {
+                    int r = 0;
+#pragma unroll
+                    for (int step = 32; step; step >>= 1)
+                        if (rpre[r + step] <= pos) r += step; // the last range that starts at or before pos
+                    const int src = rsrc[r] + pos - rpre[r];
+                    const bool fluid = r < 27;
+                    __builtin_amdgcn_global_load_lds((gptr_t)((fluid ? A.posm : A.bposm) + src), (lptr_t)(recP + p0), 16, 0, 0);
+                    if (FORCE) {
+                        const float4 *gv = fluid ? (const float4 *)A.velq + src : A.zeros;
+                        __builtin_amdgcn_global_load_lds((gptr_t)gv, (lptr_t)(recV + p0), 16, 0, 0);
                     }
-                    __syncthreads(); // (waits for the DMA)
-                    if (T > 0) {
-                        const int self = fluid ? ti - c0 : -1; // the target's own place in the chunk
-                        for (int k0 = 0; k0 < cnt; k0 += S) {
-                            const int k = k0 + slice;
+                } else if (k < cnt + 64) { // what the last slot's slices past the end read
+                    recP[k] = make_float4(NB_FAR, NB_FAR, NB_FAR, 0.f);
+                    if (FORCE) recV[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            const int nsl = T > 0 ? (int)(((float)(cnt + S - 1) + 0.5f) * __builtin_amdgcn_rcpf((float)S)) : 0;
+            uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0; // the hit words of the next 128 slots
+            auto fetch = [&](int q0) {                // (wave-uniform conditions)
+                const int nw = (min(128, nsl - q0) + 31) >> 5;
+                n0 = maskW[0];
+                n1 = nw > 1 ? maskW[64] : 0u;
+                n2 = nw > 2 ? maskW[128] : 0u;
+                n3 = nw > 3 ? maskW[192] : 0u;
+                maskW += nw * 64;
+            };
+            if (walkMasks && nsl > 0) fetch(0);
+            __syncthreads(); // (waits for the DMA)
+            if (T == 0) continue;
+            const int selfK = self - i0;
+            if (walkMasks) {
+                for (int q0 = 0; q0 < nsl; q0 += 128) {
+                    uint32_t w0 = __builtin_bitreverse32(n0), w1 = __builtin_bitreverse32(n1),
+                             w2 = __builtin_bitreverse32(n2), w3 = __builtin_bitreverse32(n3);
+                    if (q0 + 128 < nsl) fetch(q0 + 128);
+                    int kb = q0 * S + slice; // record of bit 0 of w0
+                    const int S32 = 32 * S;
+                    while (__any((w0 | w1 | w2 | w3) != 0u)) {
+                        if (w0 == 0u) {
+                            w0 = w1; w1 = w2; w2 = w3; w3 = 0u;
+                            kb += S32;
+                        }
+                        if (w0 != 0u) {
+                            const int k = kb + __builtin_ctz(w0) * S;
+                            w0 &= w0 - 1;
                             const float4 cp = recP[k];
-                            float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (FORCE) cv = recV[k];
+                            const float4 cv = recV[FORCE ? k : 0];
                             keep_b128(cp);
-                            if (FORCE) keep_b128x(cv);
-                            ps.pair(cp, cv, k != self);
+                            keep_b128x(cv);
+                            ps.pair(cp, cv, true);
                         }
                     }
+                }
+            } else {
+                int q = 0; // slots walked in this image (wave-uniform)
+                for (int k0 = 0; k0 < cnt; k0 += S) {
+                    const int k = k0 + slice;
+                    const float4 cp = recP[k];
+                    float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (FORCE) cv = recV[k];
+                    keep_b128(cp);
+                    if (FORCE) keep_b128x(cv);
+                    ps.pair(cp, cv, k != selfK);
+                    if (MASKS_OUT) {
+                        q++;
+                        if ((q & 31) == 0 && maskW) {
+                            *maskW = ~ps.hits;
+                            maskW += 64;
+                        }
+                    }
+                }
+                if (MASKS_OUT && (q & 31) != 0 && maskW) { // slot 32 j + i in bit 31 - i
+                    *maskW = (~ps.hits) << (32 - (q & 31));
+                    maskW += 64;
                 }
             }
         }
@@ -1255,7 +1391,7 @@ void k_neighbors(NbArgs A)
     for (uint32_t i = blockIdx.x; i < ncells;) {
         const int2 gc = A.gcellList[i];
         tile_lookup(ht, gc.x, A);
-        process_cell_chunked<FORCE, COUNT>(sh, ht, A, gc.y & 0xff, (gc.y >> 8) & 0xff, (gc.y >> 16) & 0xff);
+        process_cell_chunked<FORCE, COUNT>(sh, ht, A, i, gc.y & 0xff, (gc.y >> 8) & 0xff, (gc.y >> 16) & 0xff);
         __syncthreads();
         if (tid == 0) sh.next = atomicAdd(&A.ctl[A.queue + 1], 1u) + gridDim.x;
         __syncthreads();

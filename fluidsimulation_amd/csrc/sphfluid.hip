@@ -223,6 +223,7 @@ struct SphCtx {
     // neighbour plan (k_plan): block list, plans, cells of the global-memory path
     DevBuf<BlockHdr> blockList;
     DevBuf<int2> gcellList;
+    DevBuf<uint32_t> gmaskOff; // one word per entry of gcellList
     DevBuf<uint4> pool;
     bool havePlan = false;
     bool haveMasks = false; // the production density pass has run on this plan
@@ -951,7 +952,7 @@ int sph_destroy(SphCtx *c)
     release(c->rho); release(c->prs); release(c->force); release(c->zeros); release(c->dcount); release(c->fcount);
     release(c->hashes); release(c->keysEcs); release(c->cells);
     release(c->io3a); release(c->io3b); release(c->io1); release(c->ioU);
-    release(c->dmats); release(c->table); release(c->btable); release(c->ttable); release(c->tileList); release(c->tileCtl); release(c->blockList); release(c->gcellList); release(c->pool);
+    release(c->dmats); release(c->table); release(c->btable); release(c->ttable); release(c->tileList); release(c->tileCtl); release(c->blockList); release(c->gcellList); release(c->gmaskOff); release(c->pool);
     release(c->bpos3); release(c->bpar3); release(c->bposmIn); release(c->bposm);
     release(c->bkeysA); release(c->bkeysB); release(c->bvalsA); release(c->bvalsB);
     release(c->boxState); release(c->devBoxes); release(c->bodyImpulse); release(c->boxAabb); release(c->chunkAabb); release(c->bodyVelA); release(c->bodyVelB); release(c->bodyNc);
@@ -1420,7 +1421,8 @@ static NbArgs neighbor_args(SphCtx *c, const SphParams *p, int cap)
     A.blockList = c->blockList.p;
     A.blockCap = (int)std::min<size_t>(c->blockList.cap, 1u << 30);
     A.gcellList = c->gcellList.p;
-    A.gcellCap = (int)std::min<size_t>(c->gcellList.cap, 1u << 30);
+    A.gcellCap = (int)std::min<size_t>(std::min(c->gcellList.cap, c->gmaskOff.cap), 1u << 30);
+    A.gmaskOff = c->gmaskOff.p;
     A.pool = c->pool.p;
     A.poolCap = (uint32_t)std::min<size_t>(c->pool.cap, 0xffffffffu);
     return A;
@@ -1453,7 +1455,9 @@ static int ensure_plan(SphCtx *c, const SphParams *p, hipStream_t stream = nullp
     // list must not look like blocks either)
     if (!rc && c->blockList.p != listWas)
         HIPCHK(c, hipMemsetAsync(c->blockList.p, 0, c->blockList.cap * sizeof(BlockHdr), stream));
-    if (!rc) rc = ensure(c, c->gcellList, (c->fallbackCap >= 0 ? N : (N + (size_t)c->nb) / 40) + 64);
+    const size_t gcells = (c->fallbackCap >= 0 ? N : (N + (size_t)c->nb) / 40) + 64;
+    if (!rc) rc = ensure(c, c->gcellList, gcells);
+    if (!rc) rc = ensure(c, c->gmaskOff, gcells);
     size_t poolUnits = (tilesBound * 2560 + cellsBound * 352 + N * 128) / 16 + 1024 + (size_t)grid * NB_POOL_PIECE;
     if (c->poolLimit > 0) poolUnits = std::min<size_t>(poolUnits, (size_t)c->poolLimit); // (tests)
     if (!rc) rc = ensure(c, c->pool, poolUnits, c->poolLimit <= 0);
