@@ -85,6 +85,9 @@
 #endif
 #ifndef NB_CHUNK
 #define NB_CHUNK 4 // blocks per work-queue request
+#define NB_GRUN 32   // entries of the crowded-cell list a plan workgroup takes at a time
+#define NB_GQUEUE 4  // crowded cells per work-queue request
+#define NB_GPIECE 2048 // 16-byte units of pool a neighbour workgroup takes at a time for hit masks of crowded cells
 #endif
 #ifndef NB_DLB
 #define NB_DLB 5 // waves per SIMD the density kernel's register allocation must allow
@@ -167,6 +170,7 @@ struct NbArgs {
     uint4 *pool;              // plans
     uint32_t poolCap;         // in 16-byte units
     uint32_t *gmaskOff;       // per cell of gcellList: pool offset of its hit masks (0xffffffff: none)
+    int cap1;     // the same for blocks of a single cell (denser cells take the streamed path)
 };
 
 __device__ __forceinline__ int wrapi(int c, int g) { return c < 0 ? c + g : (c >= g ? c - g : c); }
@@ -573,7 +577,7 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
     const int rincl = wave_incl_scan(rsum);
     const int total = __builtin_amdgcn_readlane(rincl, 63);
     PT_MARK(2);
-    if (total > A.cap) return false;
+    if (total > (ncells == 1 ? A.cap1 : A.cap)) return false;
     const int rex[3] = {rincl - rsum, rincl - rsum + rc[0], rincl - rsum + rc[0] + rc[1]};
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -774,6 +778,7 @@ __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_
         }
     }
     la.tilesLeft = myTiles;
+    uint32_t gAt = 0, gEnd = 0; // lane 0: this workgroup's run of gcellList entries
 #ifdef NB_PLAN_TRACE
     PlanTrace pt;
     pt.start();
@@ -822,7 +827,13 @@ __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_
                         const int bx = 2 * xh + (q & 1), by = 2 * yh + (q >> 1);
                         if (plan_block<1, 1, 1>(sh, A, tileCur, bx, by, z, la PT_ARG)) continue;
                         if (threadIdx.x == 0 && sh.h.fc[tile_halo_index(bx + 1, by + 1, z + 1)] > 0) {
-                            const uint32_t idx = atomicAdd(&A.ctl[NB_CTL_GCELLS], 1u);
+                            // (entries are taken a run at a time: this is the one place in the
+                            // tile loop that waits for memory, see above)
+                            if (gAt == gEnd) {
+                                gAt = atomicAdd(&A.ctl[NB_CTL_GCELLS], (uint32_t)NB_GRUN);
+                                gEnd = gAt + NB_GRUN;
+                            }
+                            const uint32_t idx = gAt++;
                             if (idx < (uint32_t)A.gcellCap) {
                                 A.gcellList[idx] = make_int2(tileCur, bx | (by << 8) | (z << 16));
                                 A.gmaskOff[idx] = 0xffffffffu;
@@ -845,6 +856,8 @@ __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_
             if (i < (uint32_t)A.blockCap) A.blockList[i] = make_int4(0, 0, 0, 0);
         for (uint32_t i = la.at; i < la.at + la.n; i++) // a run requested ahead and not needed
             if (i < (uint32_t)A.blockCap) A.blockList[i] = make_int4(0, 0, 0, 0);
+        for (uint32_t i = gAt; i < gEnd; i++) // the rest of the last run of cells: no cell
+            if (i < (uint32_t)A.gcellCap) A.gcellList[i] = make_int2(-1, 0);
     }
 }
 
@@ -859,6 +872,8 @@ template <bool FORCE, bool COUNT> struct NbShared {
     float4 mfin[NB_MTAB];                // per material: finish_row
     BlockHdr hdr[NB_CHUNK];
     uint32_t next;
+    uint32_t gnext; // place in the crowded-cell list (its own word: `next` may still be read by a wave that leaves the block loop)
+    uint32_t gpoolAt, gpoolEnd; // this workgroup's piece of the pool for hit masks of crowded cells
 };
 static_assert(sizeof(HaloTab) <= NB_PLANMAX, "the global-memory path keeps the tile's halo in the plan area");
 static_assert(NB_CAP < 2048, "PlanShared::slot16 holds record indices in 11 bits");
@@ -1183,17 +1198,28 @@ __device__ void process_cell_chunked(NbShared<FORCE, COUNT> &sh, const HaloTab &
         const int incl = wave_incl_scan(n);
         rpre[lane] = lane <= 54 ? incl - n : 0x7fffffff;
         rsrc[lane] = s;
-        // One atomic per cell takes the pool space of all its groups (one per group -- a million
-        // returning atomics on one word per launch -- took 6 ms of the density pass).  No space
-        // left: no masks, the force pass walks every candidate of the cell.
+        // The pool space of all the cell's groups comes out of the workgroup's current piece (one
+        // atomic per group -- a million returning atomics on one word per launch -- took 6 ms of
+        // the density pass).  No space left: no masks, the force pass walks every candidate.
         uint32_t off = NB_GNOMASK;
         if (MASKS_OUT) {
             const int sl = ((__builtin_amdgcn_readlane(incl, 63) + 3) >> 2) * 4;
             const uint32_t units = (uint32_t)(ngroups * group_words(sl)) * 16u;
             if (lane == 0) {
-                off = atomicAdd(&A.ctl[NB_CTL_POOL], units);
-                // (the counter may run past the capacity: the sum stays far below 2^32)
-                if (off > A.poolCap || units > A.poolCap - off) off = NB_GNOMASK;
+                uint32_t at = sh.gpoolAt, end = sh.gpoolEnd;
+                if (units > end - at) {
+                    const uint32_t piece = max(units, (uint32_t)NB_GPIECE);
+                    at = atomicAdd(&A.ctl[NB_CTL_POOL], piece);
+                    end = at + piece;
+                    // (the counter may run past the capacity: the sum stays far below 2^32)
+                    if (at > A.poolCap || piece > A.poolCap - at) at = end = 0;
+                }
+                if (units <= end - at && units > 0) {
+                    off = at;
+                    at += units;
+                }
+                sh.gpoolAt = at;
+                sh.gpoolEnd = end;
                 A.gmaskOff[gi] = off;
             }
         } else if (MASKS_IN) {
@@ -1361,6 +1387,7 @@ void k_neighbors(NbArgs A)
         sh.mtab[i] = make_float4(m->negInvH2, m->negInvH, m->h2, m->thrF);
         sh.mfin[i] = finish_row<FORCE, COUNT>(m);
     }
+    if (!FORCE && !COUNT && tid == 0) sh.gpoolAt = sh.gpoolEnd = 0;
     const uint32_t nblocks = min(A.ctl[NB_CTL_BLOCKS], (uint32_t)A.blockCap);
     // blocks per request: NB_CHUNK when there is plenty of work, fewer when the whole list is only
     // a few blocks per workgroup (small scenes: the work must spread over all the workgroups)
@@ -1388,14 +1415,23 @@ void k_neighbors(NbArgs A)
     // cells whose 27-cell neighbourhood overflows the LDS image
     const uint32_t ncells = min(A.ctl[NB_CTL_GCELLS], (uint32_t)A.gcellCap);
     HaloTab &ht = *(HaloTab *)sh.plan;
-    for (uint32_t i = blockIdx.x; i < ncells;) {
+    // (NB_GQUEUE cells per request, aligned; the place in the list lives in LDS, not in registers)
+    if (tid == 0) sh.gnext = blockIdx.x * NB_GQUEUE;
+    for (;;) {
+        lds_barrier();
+        const uint32_t i = sh.gnext;
+        if (i >= ncells) break;
         const int2 gc = A.gcellList[i];
-        tile_lookup(ht, gc.x, A);
-        process_cell_chunked<FORCE, COUNT>(sh, ht, A, i, gc.y & 0xff, (gc.y >> 8) & 0xff, (gc.y >> 16) & 0xff);
-        __syncthreads();
-        if (tid == 0) sh.next = atomicAdd(&A.ctl[A.queue + 1], 1u) + gridDim.x;
-        __syncthreads();
-        i = sh.next;
+        if (gc.x >= 0) { // (else: unused list entry)
+            tile_lookup(ht, gc.x, A);
+            process_cell_chunked<FORCE, COUNT>(sh, ht, A, i, gc.y & 0xff, (gc.y >> 8) & 0xff, (gc.y >> 16) & 0xff);
+        }
+        __syncthreads(); // every thread has read `next`
+        if (tid == 0) {
+            uint32_t n = i + 1;
+            if (n % NB_GQUEUE == 0) n = (atomicAdd(&A.ctl[A.queue + 1], 1u) + gridDim.x) * NB_GQUEUE;
+            sh.gnext = n;
+        }
     }
 }
 
@@ -1475,6 +1511,7 @@ __global__ void k_audit_gcells(NbArgs A, int *__restrict__ counts)
     const uint32_t ncells = min(A.ctl[NB_CTL_GCELLS], (uint32_t)A.gcellCap);
     for (uint32_t i = blockIdx.x; i < ncells; i += gridDim.x) {
         const int2 gc = A.gcellList[i];
+        if (gc.x < 0) continue; // unused list entry
         const int lx = gc.y & 0xff, ly = (gc.y >> 8) & 0xff, lz = (gc.y >> 16) & 0xff;
         const int2 r = A.table[(uint32_t)gc.x * SPH_TCELLS + (uint32_t)((lz * SPH_TY + ly) * SPH_TX + lx)];
         for (int t = r.x + (int)threadIdx.x; t < r.y; t += blockDim.x) counts[t] = -1;

@@ -228,6 +228,7 @@ struct SphCtx {
     bool havePlan = false;
     bool haveMasks = false; // the production density pass has run on this plan
     int fallbackCap = -1; // debug: LDS record cap override for the neighbour kernels
+    int cap1 = NB_CAP;    // record cap of single-cell blocks (SPHFLUID_CAP1, experiments)
     long long poolLimit = 0; // debug (SPHFLUID_POOL_LIMIT, 16-byte units): cap on the plan pool, for the overflow test
 
     // boundary
@@ -919,6 +920,7 @@ int sph_create(const SphConfig *cfg, SphCtx **out)
     c->timing = cfg ? std::min(std::max(cfg->enableTimings, 0), 2) : 0;
     c->pinHost = cfg && cfg->pinHostArrays;
     if (const char *e = getenv("SPHFLUID_POOL_LIMIT")) c->poolLimit = atoll(e);
+    if (const char *e = getenv("SPHFLUID_CAP1")) c->cap1 = std::max(0, std::min(NB_CAP, atoi(e)));
     *out = c;
     return SPH_OK;
 }
@@ -1410,6 +1412,7 @@ static NbArgs neighbor_args(SphCtx *c, const SphParams *p, int cap)
     A.gy = p->gravity[1];
     A.gz = p->gravity[2];
     A.cap = c->fallbackCap >= 0 ? std::min(c->fallbackCap, cap) : cap;
+    A.cap1 = std::min(A.cap, c->cap1);
     // window tails may read on into the next cells of the row only if no support radius exceeds
     // the cell size (then those records are farther than h from every target of the cell)
     A.overread = 1;
@@ -1455,7 +1458,8 @@ static int ensure_plan(SphCtx *c, const SphParams *p, hipStream_t stream = nullp
     // list must not look like blocks either)
     if (!rc && c->blockList.p != listWas)
         HIPCHK(c, hipMemsetAsync(c->blockList.p, 0, c->blockList.cap * sizeof(BlockHdr), stream));
-    const size_t gcells = (c->fallbackCap >= 0 ? N : (N + (size_t)c->nb) / 40) + 64;
+    // (+ a run of entries per plan workgroup: they are taken NB_GRUN at a time)
+    const size_t gcells = (c->fallbackCap >= 0 || c->cap1 < NB_CAP ? N : (N + (size_t)c->nb) / 40) + 64 + (size_t)grid * NB_GRUN;
     if (!rc) rc = ensure(c, c->gcellList, gcells);
     if (!rc) rc = ensure(c, c->gmaskOff, gcells);
     size_t poolUnits = (tilesBound * 2560 + cellsBound * 352 + N * 128) / 16 + 1024 + (size_t)grid * NB_POOL_PIECE;
