@@ -227,3 +227,118 @@ __global__ __launch_bounds__(256) void k_tile_list(const int2 *__restrict__ ttab
         tileList[off] = (uint32_t)t;
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// CELL COUNTING SORT -- what the step entry points use instead of the radix passes.
+// The keys are cell numbers and the arrays are in last step's cell order, so a step moves few
+// particles to another cell.  Three passes over the particles' 4-byte words do what the radix sort
+// needs 3 x 3 launches and 20 B per key and pass for (FluidSolver.compute:47-112 in one go):
+//   k_cell_count   every run of equal keys inside a wave takes its places in the cell with ONE
+//                  atomic (about ten per wave), rank[i] = place inside the cell     reads 4, writes 4 B
+//   k_cell_sums / k_cell_scan_sums / k_cell_table   exclusive scan of the cell counts -> the
+//                  (start, end) tables of MapTable, per cell and per tile           12 B per CELL
+//   k_cell_place   perm[start(key) + rank] = i, sorted keys                         reads 8, writes 8 B
+// The order INSIDE a cell is the arrival order of the atomics, i.e. arbitrary: k_reorder re-ranks
+// every cell by particle id (it always has), so the resident order stays "stable by (cell, id)"
+// and nothing downstream sees the difference.  sph_radix_sort / sph_sort_pairs keep the radix sort
+// (their permutation is the stable one the oracle gives).
+#define CS_CELLS_PER_BLOCK 1024 // 256 threads x 4 cells
+
+__global__ __launch_bounds__(256) void k_cell_count(const uint32_t *__restrict__ keys, int n,
+                                                    uint32_t *__restrict__ counts,
+                                                    uint32_t *__restrict__ rank)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = lane_id();
+    const bool valid = i < n;
+    const uint32_t key = valid ? keys[i] : 0xffffffffu; // (no cell has this number)
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || key != prev;
+    const unsigned long long heads = __ballot(head);
+    // my run: from the last head at or below this lane to the next head above it
+    const unsigned long long upto = heads & (~0ull >> (63 - lane));
+    const int start = 63 - __clzll(upto);
+    const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+    const int next = above ? lane + 1 + __builtin_ctzll(above) : 64;
+    uint32_t base = 0;
+    if (head && valid) base = atomicAdd(&counts[key], (uint32_t)(next - lane));
+    base = __shfl(base, start, 64);
+    if (valid) rank[i] = base + (uint32_t)(lane - start);
+}
+
+// sums of CS_CELLS_PER_BLOCK counts (ncells4 = number of uint4 quads of counts, zero-padded)
+__global__ __launch_bounds__(256) void k_cell_sums(const uint4 *__restrict__ counts4, int nquads,
+                                                   uint32_t *__restrict__ blockSums)
+{
+    __shared__ uint32_t tmp[RS_WAVES];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    uint32_t s = 0;
+    if (q < nquads) {
+        const uint4 c = counts4[q];
+        s = (c.x + c.y) + (c.z + c.w);
+    }
+    uint32_t total;
+    block_excl_scan_256(s, tmp, &total);
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
+}
+
+// one block: in-place exclusive scan of the block sums
+__global__ __launch_bounds__(RS_THREADS) void k_cell_scan_sums(uint32_t *__restrict__ blockSums, int nblocks)
+{
+    __shared__ uint32_t tmp[RS_WAVES];
+    const int tid = threadIdx.x;
+    const int per = (nblocks + RS_THREADS - 1) / RS_THREADS;
+    const int lo = min(tid * per, nblocks), hi = min(lo + per, nblocks);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; i++) sum += blockSums[i];
+    uint32_t run = block_excl_scan_256(sum, tmp, nullptr);
+    for (int i = lo; i < hi; i++) {
+        const uint32_t c = blockSums[i];
+        blockSums[i] = run;
+        run += c;
+    }
+}
+
+// table[c] = (start, end) of cell c, (0, 0) for an empty one, as k_map_table leaves it; the same
+// per tile of SPH_TCELLS = 32 consecutive cells (eight threads).  cells is a multiple of 32.
+__global__ __launch_bounds__(256) void k_cell_table(const uint4 *__restrict__ counts4, int nquads,
+                                                    const uint32_t *__restrict__ blockSums, int cells,
+                                                    int2 *__restrict__ table, int2 *__restrict__ ttable)
+{
+    static_assert(SPH_TCELLS == 32, "a tile is the cells of eight threads");
+    __shared__ uint32_t tmp[RS_WAVES];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    uint4 c = make_uint4(0, 0, 0, 0);
+    if (q < nquads) c = counts4[q];
+    const uint32_t s = (c.x + c.y) + (c.z + c.w);
+    const uint32_t at = blockSums[blockIdx.x] + block_excl_scan_256(s, tmp, nullptr);
+    // the tile's particles: the sum over its eight threads (aligned groups of eight lanes)
+    uint32_t ts = s;
+    ts += __shfl_xor(ts, 1, 64);
+    ts += __shfl_xor(ts, 2, 64);
+    ts += __shfl_xor(ts, 4, 64);
+    const int cell0 = q * 4;
+    if (cell0 >= cells) return; // (the padding, and the bucket of the dead records behind the cells)
+    const int a0 = (int)at, a1 = a0 + (int)c.x, a2 = a1 + (int)c.y, a3 = a2 + (int)c.z, a4 = a3 + (int)c.w;
+    int4 lo = make_int4(c.x ? a0 : 0, c.x ? a1 : 0, c.y ? a1 : 0, c.y ? a2 : 0);
+    int4 hi = make_int4(c.z ? a2 : 0, c.z ? a3 : 0, c.w ? a3 : 0, c.w ? a4 : 0);
+    int4 *out = (int4 *)(table + cell0);
+    out[0] = lo;
+    out[1] = hi;
+    if ((threadIdx.x & 7) == 0) ttable[cell0 / SPH_TCELLS] = ts ? make_int2(a0, a0 + (int)ts) : make_int2(0, 0);
+}
+
+// places every particle: deadStart = first slot of the records whose key is `cells` (slab mode:
+// dead ghosts, cut off by the caller)
+__global__ __launch_bounds__(256) void k_cell_place(const uint32_t *__restrict__ keys,
+                                                    const uint32_t *__restrict__ rank, int n,
+                                                    const int2 *__restrict__ table, uint32_t cells,
+                                                    uint32_t deadStart, uint32_t *__restrict__ perm,
+                                                    uint32_t *__restrict__ skeys)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t key = keys[i];
+    const uint32_t dst = (key < cells ? (uint32_t)table[key].x : deadStart) + rank[i];
+    perm[dst] = (uint32_t)i;
+    skeys[dst] = key;
+}

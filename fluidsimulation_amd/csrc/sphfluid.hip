@@ -224,6 +224,8 @@ struct SphCtx {
     DevBuf<BlockHdr> blockList;
     DevBuf<int2> gcellList;
     DevBuf<uint32_t> gmaskOff; // one word per entry of gcellList
+    DevBuf<uint32_t> cellCounts, cellSums; // counting sort of the step entry points (sph_sort.h)
+    bool radixInSteps = false;  // SPHFLUID_STEP_SORT=radix: the step entry points sort like sph_radix_sort
     DevBuf<uint4> pool;
     bool havePlan = false;
     bool haveMasks = false; // the production density pass has run on this plan
@@ -920,6 +922,7 @@ int sph_create(const SphConfig *cfg, SphCtx **out)
     c->timing = cfg ? std::min(std::max(cfg->enableTimings, 0), 2) : 0;
     c->pinHost = cfg && cfg->pinHostArrays;
     if (const char *e = getenv("SPHFLUID_POOL_LIMIT")) c->poolLimit = atoll(e);
+    if (const char *e = getenv("SPHFLUID_STEP_SORT")) c->radixInSteps = strcmp(e, "radix") == 0;
     if (const char *e = getenv("SPHFLUID_CAP1")) c->cap1 = std::max(0, std::min(NB_CAP, atoi(e)));
     *out = c;
     return SPH_OK;
@@ -954,7 +957,7 @@ int sph_destroy(SphCtx *c)
     release(c->rho); release(c->prs); release(c->force); release(c->zeros); release(c->dcount); release(c->fcount);
     release(c->hashes); release(c->keysEcs); release(c->cells);
     release(c->io3a); release(c->io3b); release(c->io1); release(c->ioU);
-    release(c->dmats); release(c->table); release(c->btable); release(c->ttable); release(c->tileList); release(c->tileCtl); release(c->blockList); release(c->gcellList); release(c->gmaskOff); release(c->pool);
+    release(c->dmats); release(c->table); release(c->btable); release(c->ttable); release(c->tileList); release(c->tileCtl); release(c->blockList); release(c->gcellList); release(c->gmaskOff); release(c->cellCounts); release(c->cellSums); release(c->pool);
     release(c->bpos3); release(c->bpar3); release(c->bposmIn); release(c->bposm);
     release(c->bkeysA); release(c->bkeysB); release(c->bvalsA); release(c->bvalsB);
     release(c->boxState); release(c->devBoxes); release(c->bodyImpulse); release(c->boxAabb); release(c->chunkAabb); release(c->bodyVelA); release(c->bodyVelB); release(c->bodyNc);
@@ -1367,6 +1370,69 @@ int sph_map_table(SphCtx *c)
     return SPH_OK;
 }
 
+// Sort + tables of the step entry points: the cell counting sort of sph_sort.h (the stage calls
+// above keep the radix sort and its stable permutation).  Leaves what sph_radix_sort and
+// sph_map_table leave: sortedKeys / sortedVals (a sorting permutation; the order inside a cell is
+// arbitrary, sph_reorder ranks every cell by particle id), table, ttable, tileList.
+static int sort_and_table(SphCtx *c)
+{
+    int rc;
+    if (c->radixInSteps) {
+        if ((rc = sph_radix_sort(c))) return rc;
+        return sph_map_table(c);
+    }
+    if (!c->haveKeys) return fail(c, SPH_E_INVALID, "sort before sph_hash_position");
+    const int n = c->n, cells = c->grid.cells;
+    const int nquads = (cells + 1 + 3) / 4; // (+ 1: slab mode's dead ghosts carry key = cells)
+    const int nb = blocks_for(nquads, 256);
+    rc = ensure(c, c->cellCounts, (size_t)nquads * 4);
+    if (!rc) rc = ensure(c, c->cellSums, (size_t)nb);
+    if (!rc) rc = ensure(c, c->table, (size_t)cells);
+    if (!rc) rc = ensure(c, c->ttable, (size_t)c->grid.tiles);
+    if (!rc) rc = ensure(c, c->tileList, (size_t)c->grid.tiles);
+    if (!rc && !c->tileCtl.p) {
+        rc = ensure(c, c->tileCtl, SPH_QUEUE_SLOTS + 1, false);
+        if (!rc) HIPCHK(c, hipMemsetAsync(c->tileCtl.p, 0, (SPH_QUEUE_SLOTS + 1) * sizeof(uint32_t), c->stream));
+    }
+    if (rc) return rc;
+    rc = prepare_boundary(c);
+    if (rc) return rc;
+    {
+        StageTimer t(c, SPH_T_SORT);
+        HIPCHK(c, hipMemsetAsync(c->cellCounts.p, 0, (size_t)nquads * 16, c->stream));
+        k_cell_count<<<blocks_for(n, 256), 256, 0, c->stream>>>(c->keysA.p, n, c->cellCounts.p, c->valsA.p);
+    }
+    {
+        StageTimer t(c, SPH_T_TABLE);
+        HIPCHK(c, hipMemsetAsync(c->tileCtl.p, 0, SPH_QUEUE_SLOTS * sizeof(uint32_t), c->stream));
+        c->queueNext = NB_CTL_QUEUE0;
+        c->havePlan = c->haveMasks = false;
+        k_cell_sums<<<nb, 256, 0, c->stream>>>((const uint4 *)c->cellCounts.p, nquads, c->cellSums.p);
+        k_cell_scan_sums<<<1, RS_THREADS, 0, c->stream>>>(c->cellSums.p, nb);
+        k_cell_table<<<nb, 256, 0, c->stream>>>((const uint4 *)c->cellCounts.p, nquads, c->cellSums.p, cells,
+                                                c->table.p, c->ttable.p);
+        k_tile_list<<<blocks_for(c->grid.tiles, 256), 256, 0, c->stream>>>(
+            c->ttable.p, c->grid.tiles, c->tileList.p, c->tileCtl.p);
+    }
+    {
+        StageTimer t(c, SPH_T_SORT);
+        k_cell_place<<<blocks_for(n, 256), 256, 0, c->stream>>>(
+            c->keysA.p, c->valsA.p, n, c->table.p, (uint32_t)cells, (uint32_t)(n - (c->slab ? c->nDead : 0)),
+            c->valsB.p, c->keysB.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->sortedKeys = c->keysB.p;
+    c->sortedVals = c->valsB.p;
+    if (c->slab) { // dead ghosts carry key = cells, sort to the end and are cut off here
+        c->n -= c->nDead;
+        c->nDead = 0;
+    }
+    c->haveSort = c->haveTable = true;
+    c->haveKeys = false;
+    c->ordered = false;
+    return SPH_OK;
+}
+
 int sph_reorder(SphCtx *c)
 {
     if (!c) return SPH_E_INVALID;
@@ -1641,8 +1707,7 @@ static int resident_step(SphCtx *c, const SphParams *p, bool keysReady, bool wri
     } else if ((rc = sph_hash_position(c, p))) {
         return rc;
     }
-    if ((rc = sph_radix_sort(c))) return rc;
-    if ((rc = sph_map_table(c))) return rc;
+    if ((rc = sort_and_table(c))) return rc;
     // the plan needs the tables only: it runs on the second stream beside the reorder pass
     // (one is bound by latency, the other by HBM)
     const bool side = c->stream2 != nullptr;
@@ -1698,8 +1763,7 @@ int sph_step(SphCtx *c, const SphParams *p, float *pos, float *vel, const float 
     if (rc) return rc;
     if ((rc = sph_upload(c, pos, vel, invMass, params, N, p->gridSize))) return rc;
     if ((rc = sph_hash_position(c, p))) return rc;
-    if ((rc = sph_radix_sort(c))) return rc;
-    if ((rc = sph_map_table(c))) return rc;
+    if ((rc = sort_and_table(c))) return rc;
     if ((rc = sph_reorder(c))) return rc;
     if ((rc = sph_compute_density_and_pressure(c, p))) return rc;
     if ((rc = sph_compute_force(c, p))) return rc;
@@ -1726,8 +1790,7 @@ int sph_step_compat(SphCtx *c, const SphParams *p, const float *pos, const float
     if (!densities_out || !forces_out) return fail(c, SPH_E_INVALID, "output arrays are NULL");
     if ((rc = sph_upload(c, pos, vel, invMass, params, N, p->gridSize))) return rc;
     if ((rc = sph_hash_position(c, p))) return rc;
-    if ((rc = sph_radix_sort(c))) return rc;
-    if ((rc = sph_map_table(c))) return rc;
+    if ((rc = sort_and_table(c))) return rc;
     if ((rc = sph_reorder(c))) return rc;
     if ((rc = sph_compute_density_and_pressure(c, p))) return rc;
     if ((rc = sph_compute_force(c, p))) return rc;
@@ -2250,8 +2313,7 @@ int sph_slab_step_particles(SphCtx *c, const SphParams *p)
     if (!c->slab) return fail(c, SPH_E_INVALID, "sph_slab_step_particles before sph_slab_upload");
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = sph_hash_position(c, p))) return rc;
-    if ((rc = sph_radix_sort(c))) return rc;
-    if ((rc = sph_map_table(c))) return rc;
+    if ((rc = sort_and_table(c))) return rc;
     if ((rc = sph_reorder(c))) return rc;
     if ((rc = sph_compute_density_and_pressure(c, p))) return rc;
     if ((rc = sph_compute_force(c, p))) return rc;
