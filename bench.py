@@ -21,9 +21,8 @@ sys.path.insert(0, ROOT)
 from fluidsimulation_amd import native, scene  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# algorithmic bytes per fluid particle per launch of each stage.  The sort is
-# quoted as SURVEY prescribes, 4 + 16 * passes (one histogram read), although ours re-reads the keys
-# for the histogram of every pass (20 * passes moved): the lower figure is the one priced.
+# algorithmic bytes per fluid particle per launch of each stage (the sort of the
+# step entry points is priced where `alg` is built, further down).
 ALG_BYTES = {"keys": 20, "table": 6, "reorder": 52, "density": 20, "force": 44, "integrate": 68}
 
 
@@ -278,9 +277,10 @@ def main():
             for k in tb["ms"]:
                 if k not in ("density", "force"):
                     stage_ms[k] = tb["ms"][k] / max(tb["steps"], 1)
-        _, _, key_bits, _ = ctx.get_grid()
-        passes = (key_bits + 7) // 8
-        alg = dict(ALG_BYTES, sort=4 + 16 * passes)
+        # sort inside the step entry points: counting sort by cell, 4 + 4 (count: key in, place out)
+        # + 8 + 8 (placement: key and place in, permutation and sorted key out) bytes per particle
+        # (SURVEY section 8d prices a radix sort, 4 + 16 x passes = 52: sph_radix_sort still is one)
+        alg = dict(ALG_BYTES, sort=24)
         dom = max(("density", "force"), key=lambda k: stage_ms[k])
         achieved = alg[dom] * n / (stage_ms[dom] * 1e-3) / 1e9
         step_alg = sum(alg.values())
@@ -299,9 +299,9 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, a.config, n) if world == 1 else None,
                          "limiter": "fp32 VALU issue, not HBM: SQ_INSTS_VALU x 2.6 cycles (the measured "
-                                    "issue rate, profiles/r2_microbench_valu.txt) is 0.88 of the density "
-                                    "kernel's SIMD cycles and 0.81 of the force kernel's "
-                                    "(profiles/r3_b_C3_rocprofv3_summary.txt); `traffic` is that profile's "
+                                    "issue rate, profiles/r2_microbench_valu.txt) is 0.87 of the density "
+                                    "kernel's SIMD cycles and 0.80 of the force kernel's "
+                                    "(profiles/r3_c_C3_rocprofv3_summary.txt); `traffic` is that profile's "
                                     "PMC figure (2 x FETCH_SIZE + WRITE_SIZE), not measured in this run",
                          "alg_bytes_per_particle": alg[dom],
                          "avg_launch_ms": stage_ms[dom]},
