@@ -1161,6 +1161,61 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
 #ifndef NB_GGROUPMIN
 #define NB_GGROUPMIN NB_MAXWAVES
 #endif
+// shape of a crowded cell's work, the same in both passes and in the audit kernel
+__device__ __forceinline__ void gcell_groups(int ncell, int &per, int &ngroups)
+{
+    const int ngroups0 = max(NB_GGROUPMIN, (ncell + 31) >> 5);
+    per = (ncell + ngroups0 - 1) / ngroups0;
+    ngroups = (ncell + per - 1) / per;
+}
+// mask words of one group (sfull slices) for a stream of sl records: per image, one word per 32 slots
+__device__ __forceinline__ int gcell_group_words(int sl, int sfull)
+{
+    const int full = sl / NB_GCHUNK, last = sl - full * NB_GCHUNK;
+    return full * ((div_small(NB_GCHUNK + sfull - 1, sfull) + 31) >> 5) + ((div_small(last + sfull - 1, sfull) + 31) >> 5);
+}
+// the stride K of the scattered order: next to Q / golden ratio, coprime to Q
+__device__ __forceinline__ int gcell_stride(int nquads)
+{
+    int stride = max(1, (int)((float)nquads * 0.6180339887f));
+    for (;; stride++) {
+        int a = stride, b = nquads;
+        while (b) { const int t = a % b; a = b; b = t; }
+        if (a == 1) break;
+    }
+    return stride;
+}
+// place in the images -> place in the stream
+__device__ __forceinline__ int gcell_stream_pos(int at, int stride, int nquads)
+{
+    return (int)((uint32_t)((at >> 2) * stride) % (uint32_t)nquads) * 4 + (at & 3);
+}
+// the stream's range table (one wave): rpre[r] = stream position of range r (r = 54: the end, then
+// INT_MAX), rsrc[r] = its first record in posm (r < 27) or bposm.  Returns the stream's length.
+__device__ __forceinline__ int gcell_range_table(const HaloTab &ht, int f, int lane, int *rpre, int *rsrc)
+{
+    int n = 0, s = 0;
+    if (lane < 54) {
+        const int c27 = lane < 27 ? lane : lane - 27;
+        const int h = f + ((c27 / 9) - 1) * (NB_HX * NB_HY) + (((c27 / 3) % 3) - 1) * NB_HX + (c27 % 3) - 1;
+        s = lane < 27 ? ht.fs[h] : ht.bs[h]; // fluid (index != j, :152), then boundary (:184-189)
+        n = lane < 27 ? ht.fc[h] : ht.bc[h];
+    }
+    const int incl = wave_incl_scan(n);
+    rpre[lane] = lane <= 54 ? incl - n : 0x7fffffff;
+    rsrc[lane] = s;
+    return __builtin_amdgcn_readlane(incl, 63);
+}
+// the last range that starts at or before stream position pos
+__device__ __forceinline__ int gcell_range_of(const int *rpre, int pos)
+{
+    int r = 0;
+#pragma unroll
+    for (int step = 32; step; step >>= 1)
+        if (rpre[r + step] <= pos) r += step;
+    return r;
+}
+
 template <bool FORCE, bool COUNT>
 __device__ void process_cell_chunked(NbShared<FORCE, COUNT> &sh, const HaloTab &ht, const NbArgs &A,
                                      uint32_t gi, int lx, int ly, int lz)
@@ -1176,35 +1231,19 @@ __device__ void process_cell_chunked(NbShared<FORCE, COUNT> &sh, const HaloTab &
     // groups of at most 32 targets, at least as many as the force kernel has waves (a cell of 55
     // targets keeps eight waves busy with seven targets and nine slices each); the same groups in
     // both passes, whatever their workgroup size: the hit masks are per group
-    const int ngroups0 = max(NB_GGROUPMIN, (ncell + 31) >> 5);
-    const int per = (ncell + ngroups0 - 1) / ngroups0, ngroups = (ncell + per - 1) / per;
+    int per, ngroups;
+    gcell_groups(ncell, per, ngroups);
     const int sfull = slices_for(per); // (a last, smaller group has more slices and fewer slots)
-    // mask words of one group for a stream of sl records: per image, one word per 32 slots
-    auto group_words = [&](int sl) {
-        const int full = sl / CHUNK, last = sl - full * CHUNK;
-        return full * ((div_small(CHUNK + sfull - 1, sfull) + 31) >> 5) + ((div_small(last + sfull - 1, sfull) + 31) >> 5);
-    };
-    // the stream: rpre[r] = stream position of range r (r = 54: the end, then INT_MAX), rsrc[r] =
-    // its first record in posm (r < 27) or bposm; rsrc[60] = pool offset of the cell's hit masks
+    // the stream's range table; rsrc[60] = pool offset of the cell's hit masks
     int *rpre = (int *)(sh.plan + sizeof(HaloTab)), *rsrc = rpre + 64;
     if (w == 0) {
-        int n = 0, s = 0;
-        if (lane < 54) {
-            const int c27 = lane < 27 ? lane : lane - 27;
-            const int h = f + ((c27 / 9) - 1) * (NB_HX * NB_HY) + (((c27 / 3) % 3) - 1) * NB_HX + (c27 % 3) - 1;
-            s = lane < 27 ? ht.fs[h] : ht.bs[h]; // fluid (index != j, :152), then boundary (:184-189)
-            n = lane < 27 ? ht.fc[h] : ht.bc[h];
-        }
-        const int incl = wave_incl_scan(n);
-        rpre[lane] = lane <= 54 ? incl - n : 0x7fffffff;
-        rsrc[lane] = s;
+        const int rt = gcell_range_table(ht, f, lane, rpre, rsrc);
         // The pool space of all the cell's groups comes out of the workgroup's current piece (one
         // atomic per group -- a million returning atomics on one word per launch -- took 6 ms of
         // the density pass).  No space left: no masks, the force pass walks every candidate.
         uint32_t off = NB_GNOMASK;
         if (MASKS_OUT) {
-            const int sl = ((__builtin_amdgcn_readlane(incl, 63) + 3) >> 2) * 4;
-            const uint32_t units = (uint32_t)(ngroups * group_words(sl)) * 16u;
+            const uint32_t units = (uint32_t)(ngroups * gcell_group_words(((rt + 3) >> 2) * 4, sfull)) * 16u;
             if (lane == 0) {
                 uint32_t at = sh.gpoolAt, end = sh.gpoolEnd;
                 if (units > end - at) {
@@ -1235,17 +1274,9 @@ __device__ void process_cell_chunked(NbShared<FORCE, COUNT> &sh, const HaloTab &
     // even rate -- the mask walk of the force pass lasts as long as its busiest lane.  (The
     // counting variants keep the stream's own order: they need the target's own place in it.)
     const int nquads = (rtot + 3) >> 2, slen = nquads * 4;
-    int stride = 1;
-    if (!COUNT && NB_GSCATTER) {
-        stride = max(1, (int)((float)nquads * 0.6180339887f));
-        for (;; stride++) {
-            int a = stride, b = nquads;
-            while (b) { const int t = a % b; a = b; b = t; }
-            if (a == 1) break;
-        }
-    }
+    const int stride = (!COUNT && NB_GSCATTER) ? gcell_stride(nquads) : 1;
     const int selfBase = uniform_i(rpre[13]) - cstart; // stream position of sorted index ti: ti + selfBase
-    const uint32_t maskBase = (uint32_t)uniform_i(rsrc[60]), groupUnits = (uint32_t)group_words(slen) * 16u;
+    const uint32_t maskBase = (uint32_t)uniform_i(rsrc[60]), groupUnits = (uint32_t)gcell_group_words(slen, sfull) * 16u;
     for (int g0 = 0; g0 < ngroups; g0 += NB_WAVES) { // (workgroup-uniform)
         const int grp = g0 + w, t0 = grp * per;
         const int T = max(0, min(per, ncell - t0)); // wave-uniform; 0: the wave only helps to copy
@@ -1284,12 +1315,9 @@ __device__ void process_cell_chunked(NbShared<FORCE, COUNT> &sh, const HaloTab &
             for (int p0 = w * 64; p0 < cnt + 64; p0 += NT) { // wave-uniform
                 const int k = p0 + lane;
                 const int at = i0 + k; // place in the images -> place in the stream
-                const int pos = (int)((uint32_t)((at >> 2) * stride) % (uint32_t)nquads) * 4 + (at & 3);
+                const int pos = gcell_stream_pos(at, stride, nquads);
                 if (k < cnt && pos < rtot) {
-                    int r = 0;
-#pragma unroll
-                    for (int step = 32; step; step >>= 1)
-                        if (rpre[r + step] <= pos) r += step; // the last range that starts at or before pos
+                    const int r = gcell_range_of(rpre, pos);
                     const int src = rsrc[r] + pos - rpre[r];
                     const bool fluid = r < 27;
                     __builtin_amdgcn_global_load_lds((gptr_t)((fluid ? A.posm : A.bposm) + src), (lptr_t)(recP + p0), 16, 0, 0);
@@ -1505,15 +1533,68 @@ __global__ __launch_bounds__(64) void k_audit_masks(NbArgs A, const uint32_t *__
     }
 }
 
-// targets of the cells that took the global-memory path carry no masks: count -1
-__global__ void k_audit_gcells(NbArgs A, int *__restrict__ counts)
+// The same for the crowded cells (process_cell_chunked): their masks are per group of targets, image
+// and 32 slots, and a slot's records are found through the scattered order of the stream.  One
+// wave per cell.  A cell whose masks found no room in the pool has none: count -1.
+__global__ __launch_bounds__(64) void k_audit_gcells(NbArgs A, const uint32_t *__restrict__ oid,
+                                                     const uint32_t *__restrict__ bperm, uint32_t bndBase,
+                                                     int *__restrict__ counts,
+                                                     unsigned long long *__restrict__ idsum,
+                                                     uint32_t *__restrict__ invalid)
 {
+    __shared__ HaloTab ht;
+    __shared__ int rpre[64], rsrc[64];
+    const int lane = threadIdx.x;
     const uint32_t ncells = min(A.ctl[NB_CTL_GCELLS], (uint32_t)A.gcellCap);
     for (uint32_t i = blockIdx.x; i < ncells; i += gridDim.x) {
         const int2 gc = A.gcellList[i];
         if (gc.x < 0) continue; // unused list entry
-        const int lx = gc.y & 0xff, ly = (gc.y >> 8) & 0xff, lz = (gc.y >> 16) & 0xff;
-        const int2 r = A.table[(uint32_t)gc.x * SPH_TCELLS + (uint32_t)((lz * SPH_TY + ly) * SPH_TX + lx)];
-        for (int t = r.x + (int)threadIdx.x; t < r.y; t += blockDim.x) counts[t] = -1;
+        __syncthreads();
+        tile_lookup(ht, gc.x, A);
+        const int f = tile_halo_index((gc.y & 0xff) + 1, ((gc.y >> 8) & 0xff) + 1, ((gc.y >> 16) & 0xff) + 1);
+        const int ncell = ht.fc[f], cstart = ht.fs[f];
+        const int rtot = gcell_range_table(ht, f, lane, rpre, rsrc);
+        __syncthreads();
+        const uint32_t maskBase = A.gmaskOff[i];
+        if (maskBase == NB_GNOMASK) {
+            for (int t = lane; t < ncell; t += 64) counts[cstart + t] = -1;
+            continue;
+        }
+        int per, ngroups;
+        gcell_groups(ncell, per, ngroups);
+        const int sfull = slices_for(per);
+        const int nquads = (rtot + 3) >> 2, slen = nquads * 4;
+        const int stride = NB_GSCATTER ? gcell_stride(nquads) : 1;
+        const uint32_t groupUnits = (uint32_t)gcell_group_words(slen, sfull) * 16u;
+        for (int grp = 0; grp < ngroups; grp++) {
+            const int t0 = grp * per, T = min(per, ncell - t0), S = slices_for(T);
+            int u, slice;
+            split_lane(lane, S, u, slice);
+            if (u >= T) continue;
+            const uint32_t *maskW = (const uint32_t *)(A.pool + maskBase + (uint32_t)grp * groupUnits) + lane;
+            int cnt = 0;
+            unsigned long long sum = 0;
+            for (int i0 = 0; i0 < slen; i0 += NB_GCHUNK) {
+                const int n = min(NB_GCHUNK, slen - i0), nsl = div_small(n + S - 1, S);
+                for (int j = 0; j * 32 < nsl; j++, maskW += 64) {
+                    uint32_t m = __builtin_bitreverse32(*maskW);
+                    while (m) {
+                        const int k = (32 * j + __builtin_ctz(m)) * S + slice;
+                        m &= m - 1;
+                        const int pos = gcell_stream_pos(i0 + k, stride, nquads);
+                        if (k >= n || pos >= rtot) { // (a FAR record: no hit can be there)
+                            atomicAdd(invalid, 1u);
+                            continue;
+                        }
+                        const int r = gcell_range_of(rpre, pos), src = rsrc[r] + pos - rpre[r];
+                        if (r < 27) sum += oid[src] & 0x3fffffffu;
+                        else sum += (unsigned long long)bndBase + bperm[src];
+                        cnt++;
+                    }
+                }
+            }
+            atomicAdd(&counts[cstart + t0 + u], cnt);
+            atomicAdd(&idsum[cstart + t0 + u], sum);
+        }
     }
 }

@@ -1865,7 +1865,8 @@ static int read_mask_audit(SphCtx *c, int32_t buffer, void *out, size_t bytes)
         if (e == hipSuccess) {
             k_audit_masks<<<2048, 64, 0, c->stream>>>(A, c->oid[cur].p, c->nb > 0 ? c->bperm : nullptr,
                                                       (uint32_t)N, cnt.p, sum.p, inv.p);
-            k_audit_gcells<<<256, 64, 0, c->stream>>>(A, cnt.p);
+            k_audit_gcells<<<1024, 64, 0, c->stream>>>(A, c->oid[cur].p, c->nb > 0 ? c->bperm : nullptr,
+                                                       (uint32_t)N, cnt.p, sum.p, inv.p);
             const int nb = blocks_for(N, 256);
             if (buffer == SPH_BUF_MASK_COUNTS) {
                 k_unpack1<int><<<nb, 256, 0, c->stream>>>(cnt.p, c->oid[cur].p, N, (int *)c->io1.p);

@@ -148,8 +148,9 @@ enum {
     /* Parity audit of the PRODUCTION neighbour set: the hit masks the production density pass
      * leaves for the force pass (candidates with fma(d2, -1/h2, 1) >= 0), walked as the force
      * pass walks them.  Per particle, ECS order: number of hits (self and boundary included, the
-     * counterpart of SPH_BUF_DENSITY_COUNTS; -1 for a particle of a cell that took the
-     * global-memory path, which has no masks) and the sum of the hits' ids, fluid ids as given to
+     * counterpart of SPH_BUF_DENSITY_COUNTS; -1 for a particle of a crowded cell whose masks
+     * found no room in the plan pool: its force pass walks every candidate) and the sum of the
+     * hits' ids, fluid ids as given to
      * sph_upload, boundary particle k as N + k.  Needs the production density pass (no
      * SPH_DEBUG_COUNTS) on the current ordering. */
     SPH_BUF_MASK_COUNTS,     /* i32[N]                                                          */
@@ -162,8 +163,8 @@ typedef struct SphCtx SphCtx;
 enum {
     SPH_DEBUG_HASHES = 1, /* hash_position also writes SPH_BUF_HASHES / SPH_BUF_CELLS        */
     SPH_DEBUG_COUNTS = 2, /* density / force kernels also write the neighbour-count buffers  */
-    SPH_DEBUG_NO_LDS_TILE = 4 /* neighbour kernels take their global-memory path for every
-                                 tile (the path used when a tile's halo overflows the LDS)  */
+    SPH_DEBUG_NO_LDS_TILE = 4 /* neighbour kernels take their crowded-cell path for every cell
+                                 (the path of a cell whose 27 cells overflow the LDS image) */
 };
 
 /* ---- life cycle --------------------------------------------------------------------------

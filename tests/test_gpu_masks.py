@@ -45,13 +45,13 @@ def reference_pairs(sc):
     return i, j, d2, h2
 
 
-def audit(ctx, sc, oracle_counts=None):
+def audit(ctx, sc, oracle_counts=None, debug=0):
     n = len(sc.pos)
-    p = load_scene(ctx, sc, debug=0)
+    p = load_scene(ctx, sc, debug=debug)
     run_to_force(ctx, p)
     cnt = ctx.read(native.SPH_BUF_MASK_COUNTS).astype(np.int64)
     ids = ctx.read(native.SPH_BUF_MASK_IDSUMS)
-    assert (cnt >= 0).all(), "a cell took the global-memory path: no masks to audit"
+    assert (cnt >= 0).all(), "a crowded cell found no room for its masks in the pool: nothing to audit there"
     i, j, d2, h2 = reference_pairs(sc)
     hit = d2 < h2[i]
     ref_cnt = np.bincount(i[hit], minlength=n)
@@ -117,3 +117,29 @@ def test_production_hit_masks_on_knife_edge_pairs(ctx):
     print(f"knife edge: {nhits} reference pairs, {nband} within {BAND_ULP} ulp of h2, "
           f"{npairs} decided differently ({ntargets} particles)")
     assert nband > 200  # the scene does put pairs on the edge
+
+
+def test_production_hit_masks_of_crowded_cells(ctx):
+    """64 particles per cell (eight times the rest density): the 27-cell neighbourhood does not
+    fit the LDS image, the cells take the streamed path (process_cell_chunked) with its own mask
+    layout -- per group of targets, image and 32 slots, records in the scattered order of the
+    stream.  Same audit; near the walls the cells are thin enough to be planned blocks, so both
+    layouts are in this scene."""
+    sc = scene.dam_break(20, 20, 20, jitter_seed=77)
+    sc.pos = (sc.pos * np.float32(0.5) + np.float32(0.25)).astype(np.float32)
+    ntargets, npairs, nband, nhits = audit(ctx, sc)
+    print(f"crowded: {nhits} reference pairs, {nband} within {BAND_ULP} ulp of h2, "
+          f"{npairs} decided differently ({ntargets} particles)")
+    assert nhits > 200 * len(sc.pos)   # ~8 x 33 neighbours per particle in the bulk
+    assert npairs == 0                 # jittered: no pair on the support radius
+
+
+def test_production_hit_masks_with_every_cell_on_the_streamed_path(ctx):
+    """SPH_DEBUG_NO_LDS_TILE sends every cell down the crowded-cell path, whatever its occupancy:
+    the jittered 32k block again, now audited through that path's masks alone"""
+    g = np.load(os.path.join(GOLD, "jitter_32k.npz"))
+    sc = scene.dam_break(32, 32, 32, jitter_seed=0x5EED0003)
+    sc.vel = np.load(os.path.join(GOLD, "jitter_32k_vel.npy")).astype(np.float32)
+    ntargets, npairs, nband, nhits = audit(ctx, sc, oracle_counts=g["dcnt"],
+                                           debug=native.SPH_DEBUG_NO_LDS_TILE)
+    assert npairs == 0 and ntargets == 0
