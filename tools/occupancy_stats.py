@@ -46,5 +46,16 @@ for chunk in range(0, nsteps, 50):
     print(f"   tiles with fluid {live.sum()}, halo records mean {h.mean():.0f} p90 {np.percentile(h, 90):.0f} "
           f"p99 {np.percentile(h, 99):.0f} max {h.max()}; > 1184: {np.mean(h > 1184):.3f}, > 1792: "
           f"{np.mean(h > 1792):.3f}; own > 512: {np.mean(own[live] > 512):.4f}")
+    # per occupied cell: records in its 27 cells (what decides between a planned block and the
+    # crowded-cell path), and the share of particles and of candidate pairs on either side
+    c27 = (cs[3:, 3:, 3:] - cs[:-3, 3:, 3:] - cs[3:, :-3, 3:] - cs[3:, 3:, :-3]
+           + cs[:-3, :-3, 3:] + cs[:-3, 3:, :-3] + cs[3:, :-3, :-3] - cs[:-3, :-3, :-3])
+    occf = occ.astype(np.float64)
+    crowded = (c27 > 1184) & (occ > 0)
+    pairs = occf * c27
+    print(f"   cells on the crowded-cell path {crowded.sum()} of {nz.size}: {occf[crowded].sum() / occf.sum():.3f} of the "
+          f"particles, {pairs[crowded].sum() / pairs.sum():.3f} of the candidate pairs; candidates per particle "
+          f"{pairs.sum() / occf.sum():.0f} (crowded {pairs[crowded].sum() / max(occf[crowded].sum(), 1):.0f}, "
+          f"planned {pairs[~crowded].sum() / max(occf[~crowded].sum(), 1):.0f})")
     t = ctx.timings(); ctx.reset_timings()
     print("   stage ms/step:", {k: round(v / max(t['steps'], 1), 3) for k, v in t['ms'].items()})
