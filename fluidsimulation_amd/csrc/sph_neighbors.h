@@ -1155,6 +1155,9 @@ __device__ __forceinline__ void exec_block(NbShared<FORCE, COUNT> &sh, const NbA
 // registers and walks their set bits; the next four are in flight meanwhile.
 #define NB_GCHUNK (NB_CAP - 64) // candidate records per image; 64 FAR records follow them
 #define NB_GNOMASK 0xffffffffu
+#ifndef NB_GUNROLL
+#define NB_GUNROLL 4 // slots per iteration of the density pass's walk (divides 32)
+#endif
 #ifndef NB_GSCATTER
 #define NB_GSCATTER 1
 #endif
@@ -1369,7 +1372,32 @@ __device__ void process_cell_chunked(NbShared<FORCE, COUNT> &sh, const HaloTab &
                 }
             } else {
                 int q = 0; // slots walked in this image (wave-uniform)
-                for (int k0 = 0; k0 < cnt; k0 += S) {
+                int k0 = 0;
+                // NB_GUNROLL slots at a time, their LDS reads in flight together (a word of hit bits is
+                // 32 slots: the flush test stays once per group)
+                for (; !FORCE && k0 + NB_GUNROLL * S <= cnt; k0 += NB_GUNROLL * S) { // (density; the force pass walks masks)
+                    float4 cp[NB_GUNROLL], cv[NB_GUNROLL];
+#pragma unroll
+                    for (int g = 0; g < NB_GUNROLL; g++) {
+                        cp[g] = recP[k0 + g * S + slice];
+                        cv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (FORCE) cv[g] = recV[k0 + g * S + slice];
+                    }
+#pragma unroll
+                    for (int g = 0; g < NB_GUNROLL; g++) {
+                        keep_b128(cp[g]);
+                        if (FORCE) keep_b128x(cv[g]);
+                        ps.pair(cp[g], cv[g], k0 + g * S + slice != selfK);
+                    }
+                    if (MASKS_OUT) {
+                        q += NB_GUNROLL;
+                        if ((q & 31) == 0 && maskW) {
+                            *maskW = ~ps.hits;
+                            maskW += 64;
+                        }
+                    }
+                }
+                for (; k0 < cnt; k0 += S) {
                     const int k = k0 + slice;
                     const float4 cp = recP[k];
                     float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
