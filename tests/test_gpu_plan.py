@@ -52,3 +52,32 @@ def test_plan_pool_overflow_is_reported_not_a_fault():
         c.step_resident(p, 2)
         pos, vel = c.download()
         assert np.isfinite(pos).all() and np.isfinite(vel).all()
+
+
+def test_crowded_cells_without_room_for_their_masks_walk_every_candidate():
+    """The hit masks of a crowded cell come out of the plan pool; when it is full the cell simply
+    has none and its force pass walks every candidate (no error): same forces, and the audit
+    buffer says -1 for exactly those particles."""
+    sc = jittered_block(20, 20, 20, seed=9)
+    sc.pos = (sc.pos * np.float32(0.5) + np.float32(0.25)).astype(np.float32)  # 64 per cell
+
+    def forces(limit):
+        if limit:
+            os.environ["SPHFLUID_POOL_LIMIT"] = str(limit)
+        try:
+            with native.Context(device=0) as c:
+                p = load_scene(c, sc, debug=0)
+                run_to_force(c, p)
+                c.synchronize()
+                return c.read(native.SPH_BUF_FORCES), c.read(native.SPH_BUF_MASK_COUNTS)
+        finally:
+            os.environ.pop("SPHFLUID_POOL_LIMIT", None)
+
+    f_all, cnt_all = forces(0)
+    # (every plan workgroup takes 128 KB pieces of the pool first: room for those, little more)
+    f_some, cnt_some = forces(140000)
+    assert (cnt_all >= 0).all()
+    nomask = cnt_some < 0
+    assert 0 < nomask.sum() < len(sc.pos), f"{nomask.sum()} particles without masks"
+    np.testing.assert_array_equal(cnt_some[~nomask], cnt_all[~nomask])
+    assert_close(f_some, f_all, rtol=1e-6, what="force without masks")
