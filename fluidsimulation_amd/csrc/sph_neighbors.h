@@ -169,9 +169,26 @@ struct NbArgs {
     int gcellCap;
     uint4 *pool;              // plans
     uint32_t poolCap;         // in 16-byte units
+    uint32_t planGrid;        // workgroups of the k_plan launch that made this plan (static runs / pieces)
     uint32_t *gmaskOff;       // per cell of gcellList: pool offset of its hit masks (0xffffffff: none)
     int cap1;     // the same for blocks of a single cell (denser cells take the streamed path)
 };
+
+// The first run of block-list entries and the first piece of the pool of every plan workgroup are
+// STATIC -- workgroup b owns entries [b per, (b + 1) per), per = ceil(tiles / workgroups), and pool
+// units [b NB_POOL_PIECE, (b + 1) NB_POOL_PIECE) -- so that a launch does not begin with two
+// returning atomics per workgroup on two words (8192 of them at 88 per microsecond: ~90 us before
+// the last workgroup could write its first block).  What the counters NB_CTL_BLOCKS / NB_CTL_POOL
+// hand out lies behind these regions.
+__device__ __forceinline__ uint32_t plan_static_run(uint32_t ntiles, uint32_t grid)
+{
+    return (ntiles + grid - 1) / grid;
+}
+__device__ __forceinline__ uint32_t plan_list_base(uint32_t ntiles, uint32_t grid)
+{
+    return min(grid, ntiles) * plan_static_run(ntiles, grid);
+}
+__device__ __forceinline__ uint32_t plan_pool_base(uint32_t grid) { return grid * (uint32_t)NB_POOL_PIECE; }
 
 __device__ __forceinline__ int wrapi(int c, int g) { return c < 0 ? c + g : (c >= g ? c - g : c); }
 
@@ -543,6 +560,7 @@ __device__ __forceinline__ int div_small(int a, int b)
 // to LDS, the answer of the atomic would be waited for at once).
 struct ListAhead {
     uint32_t at = 0, n = 0; // n = 0: nothing requested
+    uint32_t base = 0;      // plan_list_base: where the runs the counter hands out begin
     int tilesLeft = 0;      // tiles this workgroup still has to plan after the current one
 };
 
@@ -646,7 +664,7 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
         const uint32_t units16 = ((uint32_t)(nh * 16 + nunits * 32 + nslots * 4) >> 4) + (uint32_t)nwords * 16;
         if (sh.poolAt + units16 > sh.poolEnd) {
             const uint32_t piece = max(units16, (uint32_t)NB_POOL_PIECE);
-            sh.poolAt = atomicAdd(&A.ctl[NB_CTL_POOL], piece);
+            sh.poolAt = plan_pool_base(gridDim.x) + atomicAdd(&A.ctl[NB_CTL_POOL], piece);
             sh.poolEnd = sh.poolAt + piece;
         }
         // The neighbour kernels walk every entry of the list, and an unused one costs them a
@@ -657,7 +675,7 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
         if (sh.listAt == sh.listEnd) {
             if (la.n == 0) {
                 la.n = (uint32_t)la.tilesLeft + 2;
-                la.at = atomicAdd(&A.ctl[NB_CTL_BLOCKS], la.n);
+                la.at = la.base + atomicAdd(&A.ctl[NB_CTL_BLOCKS], la.n);
             }
             sh.listAt = la.at;
             sh.listEnd = la.at + la.n;
@@ -674,7 +692,7 @@ __device__ __forceinline__ bool plan_block(PlanShared &sh, const NbArgs &A, int 
         const int left = (int)(sh.listEnd - sh.listAt);
         if (la.n == 0 && left < la.tilesLeft) {
             la.n = (uint32_t)min(la.tilesLeft - left + 1 + (la.tilesLeft >> 2), NB_LIST_PIECE);
-            la.at = atomicAdd(&A.ctl[NB_CTL_BLOCKS], la.n);
+            la.at = la.base + atomicAdd(&A.ctl[NB_CTL_BLOCKS], la.n);
         }
         off = ok ? (int)o : -1;
         idx = (int)i;
@@ -770,12 +788,13 @@ __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_
     const uint32_t ntiles = A.ctl[NB_CTL_TILES];
     const int myTiles = blockIdx.x < ntiles ? (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
     ListAhead la;
-    if (threadIdx.x == 0) {
-        sh.poolAt = sh.poolEnd = sh.listAt = sh.listEnd = 0;
-        if (myTiles > 0) { // first run: one entry per tile
-            la.n = (uint32_t)myTiles;
-            la.at = atomicAdd(&A.ctl[NB_CTL_BLOCKS], la.n);
-        }
+    la.base = plan_list_base(ntiles, gridDim.x);
+    if (threadIdx.x == 0) { // the static first piece and run (about one entry per tile)
+        const uint32_t per = myTiles > 0 ? plan_static_run(ntiles, gridDim.x) : 0u;
+        sh.poolAt = blockIdx.x * (uint32_t)NB_POOL_PIECE;
+        sh.poolEnd = sh.poolAt + (uint32_t)NB_POOL_PIECE;
+        sh.listAt = blockIdx.x * per;
+        sh.listEnd = sh.listAt + per;
     }
     la.tilesLeft = myTiles;
     uint32_t gAt = 0, gEnd = 0; // lane 0: this workgroup's run of gcellList entries
@@ -1251,7 +1270,7 @@ __device__ void process_cell_chunked(NbShared<FORCE, COUNT> &sh, const HaloTab &
                 uint32_t at = sh.gpoolAt, end = sh.gpoolEnd;
                 if (units > end - at) {
                     const uint32_t piece = max(units, (uint32_t)NB_GPIECE);
-                    at = atomicAdd(&A.ctl[NB_CTL_POOL], piece);
+                    at = plan_pool_base(A.planGrid) + atomicAdd(&A.ctl[NB_CTL_POOL], piece);
                     end = at + piece;
                     // (the counter may run past the capacity: the sum stays far below 2^32)
                     if (at > A.poolCap || piece > A.poolCap - at) at = end = 0;
@@ -1444,7 +1463,7 @@ void k_neighbors(NbArgs A)
         sh.mfin[i] = finish_row<FORCE, COUNT>(m);
     }
     if (!FORCE && !COUNT && tid == 0) sh.gpoolAt = sh.gpoolEnd = 0;
-    const uint32_t nblocks = min(A.ctl[NB_CTL_BLOCKS], (uint32_t)A.blockCap);
+    const uint32_t nblocks = min(plan_list_base(A.ctl[NB_CTL_TILES], A.planGrid) + A.ctl[NB_CTL_BLOCKS], (uint32_t)A.blockCap);
     // blocks per request: NB_CHUNK when there is plenty of work, fewer when the whole list is only
     // a few blocks per workgroup (small scenes: the work must spread over all the workgroups)
     const uint32_t chunk = min((uint32_t)NB_CHUNK, max(1u, nblocks / (4u * gridDim.x)));
@@ -1507,7 +1526,7 @@ __global__ __launch_bounds__(64) void k_audit_masks(NbArgs A, const uint32_t *__
                                                     uint32_t *__restrict__ invalid)
 {
     const int lane = threadIdx.x;
-    const uint32_t nblocks = min(A.ctl[NB_CTL_BLOCKS], (uint32_t)A.blockCap);
+    const uint32_t nblocks = min(plan_list_base(A.ctl[NB_CTL_TILES], A.planGrid) + A.ctl[NB_CTL_BLOCKS], (uint32_t)A.blockCap);
     for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const BlockHdr hdr = A.blockList[b];
         if (hdr.w == 0) continue;

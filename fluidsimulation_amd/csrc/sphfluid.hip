@@ -224,6 +224,7 @@ struct SphCtx {
     DevBuf<BlockHdr> blockList;
     DevBuf<int2> gcellList;
     DevBuf<uint32_t> gmaskOff; // one word per entry of gcellList
+    int planGrid = 1;          // workgroups of the last k_plan launch
     DevBuf<uint32_t> cellCounts, cellSums; // counting sort of the step entry points (sph_sort.h)
     bool radixInSteps = false;  // SPHFLUID_STEP_SORT=radix: the step entry points sort like sph_radix_sort
     DevBuf<uint4> pool;
@@ -1492,6 +1493,7 @@ static NbArgs neighbor_args(SphCtx *c, const SphParams *p, int cap)
     A.gcellList = c->gcellList.p;
     A.gcellCap = (int)std::min<size_t>(std::min(c->gcellList.cap, c->gmaskOff.cap), 1u << 30);
     A.gmaskOff = c->gmaskOff.p;
+    A.planGrid = (uint32_t)c->planGrid;
     A.pool = c->pool.p;
     A.poolCap = (uint32_t)std::min<size_t>(c->pool.cap, 0xffffffffu);
     return A;
@@ -1529,10 +1531,14 @@ static int ensure_plan(SphCtx *c, const SphParams *p, hipStream_t stream = nullp
     if (!rc) rc = ensure(c, c->gcellList, gcells);
     if (!rc) rc = ensure(c, c->gmaskOff, gcells);
     size_t poolUnits = (tilesBound * 2560 + cellsBound * 352 + N * 128) / 16 + 1024 + (size_t)grid * NB_POOL_PIECE;
+    // (SPH_DEBUG_NO_LDS_TILE sends every cell down the crowded-cell path, whose masks are per group
+    // of targets: a word of 64 lanes per target of a sparse cell)
+    if (c->fallbackCap >= 0) poolUnits += N * 512 / 16;
     if (c->poolLimit > 0) poolUnits = std::min<size_t>(poolUnits, (size_t)c->poolLimit); // (tests)
     if (!rc) rc = ensure(c, c->pool, poolUnits, c->poolLimit <= 0);
     if (rc) return rc;
     StageTimer t(c, SPH_T_PLAN, stream);
+    c->planGrid = grid;
     NbArgs A = neighbor_args(c, p, NB_CAP);
     if (c->poolLimit > 0) A.poolCap = std::min<uint32_t>(A.poolCap, (uint32_t)c->poolLimit);
     k_plan<<<grid, NB_PTHREADS, 0, stream>>>(A);
