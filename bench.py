@@ -300,8 +300,8 @@ def main():
                          "traffic": measured_traffic(dom, a.config, n) if world == 1 else None,
                          "limiter": "fp32 VALU issue, not HBM: SQ_INSTS_VALU x 2.6 cycles (the measured "
                                     "issue rate, profiles/r2_microbench_valu.txt) is 0.87 of the density "
-                                    "kernel's SIMD cycles and 0.80 of the force kernel's "
-                                    "(profiles/r3_c_C3_rocprofv3_summary.txt); `traffic` is that profile's "
+                                    "kernel's SIMD cycles and 0.81 of the force kernel's "
+                                    "(profiles/r3_d_C3_rocprofv3_summary.txt); `traffic` is that profile's "
                                     "PMC figure (2 x FETCH_SIZE + WRITE_SIZE), not measured in this run",
                          "alg_bytes_per_particle": alg[dom],
                          "avg_launch_ms": stage_ms[dom]},

@@ -75,7 +75,9 @@
 #define NB_MAXUNITS 64   // (cell, part) units per block
 #define NB_SLOTCAP 1408  // slot-table entries per block
 #define NB_MTAB 64       // materials whose loop constants are cached in LDS
+#ifndef NB_POOL_PIECE
 #define NB_POOL_PIECE 8192 // 16-byte units of plan pool a plan workgroup takes at a time (128 KB)
+#endif
 #define NB_LIST_PIECE 16   // most block-list entries a plan workgroup can leave unused
 #ifndef NB_PLAN_WAVES
 #define NB_PLAN_WAVES 4 // waves per SIMD the plan kernel's register allocation must allow
