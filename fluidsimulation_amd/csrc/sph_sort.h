@@ -244,25 +244,42 @@ __global__ __launch_bounds__(256) void k_tile_list(const int2 *__restrict__ ttab
 // (their permutation is the stable one the oracle gives).
 #define CS_CELLS_PER_BLOCK 1024 // 256 threads x 4 cells
 
+#define CS_COUNT_ITEMS 4 // keys per thread: the returning atomics are latency, not throughput --
+                         // four independent ones in flight per wave instead of one
 __global__ __launch_bounds__(256) void k_cell_count(const uint32_t *__restrict__ keys, int n,
                                                     uint32_t *__restrict__ counts,
                                                     uint32_t *__restrict__ rank)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, lane = lane_id();
-    const bool valid = i < n;
-    const uint32_t key = valid ? keys[i] : 0xffffffffu; // (no cell has this number)
-    const uint32_t prev = __shfl_up(key, 1, 64);
-    const bool head = lane == 0 || key != prev;
-    const unsigned long long heads = __ballot(head);
-    // my run: from the last head at or below this lane to the next head above it
-    const unsigned long long upto = heads & (~0ull >> (63 - lane));
-    const int start = 63 - __clzll(upto);
-    const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
-    const int next = above ? lane + 1 + __builtin_ctzll(above) : 64;
-    uint32_t base = 0;
-    if (head && valid) base = atomicAdd(&counts[key], (uint32_t)(next - lane));
-    base = __shfl(base, start, 64);
-    if (valid) rank[i] = base + (uint32_t)(lane - start);
+    const int lane = lane_id();
+    const long first = (long)blockIdx.x * (256 * CS_COUNT_ITEMS) + threadIdx.x;
+    uint32_t key[CS_COUNT_ITEMS], base[CS_COUNT_ITEMS];
+    int start[CS_COUNT_ITEMS];
+    bool valid[CS_COUNT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < CS_COUNT_ITEMS; j++) {
+        const long i = first + j * 256;
+        valid[j] = i < n;
+        key[j] = valid[j] ? keys[i] : 0xffffffffu; // (no cell has this number)
+    }
+    // every run of equal keys inside a wave takes its places in the cell with one atomic, issued
+    // by its first lane (a run: from a head to the next head)
+#pragma unroll
+    for (int j = 0; j < CS_COUNT_ITEMS; j++) {
+        const uint32_t prev = __shfl_up(key[j], 1, 64);
+        const bool head = lane == 0 || key[j] != prev;
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long upto = heads & (~0ull >> (63 - lane));
+        start[j] = 63 - __clzll(upto);
+        const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+        const int next = above ? lane + 1 + __builtin_ctzll(above) : 64;
+        base[j] = 0;
+        if (head && valid[j]) base[j] = atomicAdd(&counts[key[j]], (uint32_t)(next - lane));
+    }
+#pragma unroll
+    for (int j = 0; j < CS_COUNT_ITEMS; j++) {
+        const uint32_t b = __shfl(base[j], start[j], 64);
+        if (valid[j]) rank[first + j * 256] = b + (uint32_t)(lane - start[j]);
+    }
 }
 
 // sums of CS_CELLS_PER_BLOCK counts (ncells4 = number of uint4 quads of counts, zero-padded)
@@ -329,16 +346,34 @@ __global__ __launch_bounds__(256) void k_cell_table(const uint4 *__restrict__ co
 
 // places every particle: deadStart = first slot of the records whose key is `cells` (slab mode:
 // dead ghosts, cut off by the caller)
+#define CS_PLACE_ITEMS 4 // particles per thread (their look-ups in flight together)
 __global__ __launch_bounds__(256) void k_cell_place(const uint32_t *__restrict__ keys,
                                                     const uint32_t *__restrict__ rank, int n,
                                                     const int2 *__restrict__ table, uint32_t cells,
                                                     uint32_t deadStart, uint32_t *__restrict__ perm,
                                                     uint32_t *__restrict__ skeys)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t key = keys[i];
-    const uint32_t dst = (key < cells ? (uint32_t)table[key].x : deadStart) + rank[i];
-    perm[dst] = (uint32_t)i;
-    skeys[dst] = key;
+    const long first = (long)blockIdx.x * (256 * CS_PLACE_ITEMS) + threadIdx.x;
+    uint32_t key[CS_PLACE_ITEMS], r[CS_PLACE_ITEMS], st[CS_PLACE_ITEMS];
+#pragma unroll
+    for (int j = 0; j < CS_PLACE_ITEMS; j++) {
+        const long i = first + j * 256;
+        key[j] = r[j] = 0;
+        if (i < n) {
+            key[j] = keys[i];
+            r[j] = rank[i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CS_PLACE_ITEMS; j++)
+        st[j] = (first + j * 256 < n && key[j] < cells) ? (uint32_t)table[key[j]].x : deadStart;
+#pragma unroll
+    for (int j = 0; j < CS_PLACE_ITEMS; j++) {
+        const long i = first + j * 256;
+        if (i < n) {
+            const uint32_t dst = st[j] + r[j];
+            perm[dst] = (uint32_t)i;
+            skeys[dst] = key[j];
+        }
+    }
 }

@@ -1401,7 +1401,7 @@ static int sort_and_table(SphCtx *c)
     {
         StageTimer t(c, SPH_T_SORT);
         HIPCHK(c, hipMemsetAsync(c->cellCounts.p, 0, (size_t)nquads * 16, c->stream));
-        k_cell_count<<<blocks_for(n, 256), 256, 0, c->stream>>>(c->keysA.p, n, c->cellCounts.p, c->valsA.p);
+        k_cell_count<<<blocks_for(n, 256 * CS_COUNT_ITEMS), 256, 0, c->stream>>>(c->keysA.p, n, c->cellCounts.p, c->valsA.p);
     }
     {
         StageTimer t(c, SPH_T_TABLE);
@@ -1417,7 +1417,7 @@ static int sort_and_table(SphCtx *c)
     }
     {
         StageTimer t(c, SPH_T_SORT);
-        k_cell_place<<<blocks_for(n, 256), 256, 0, c->stream>>>(
+        k_cell_place<<<blocks_for(n, 256 * CS_PLACE_ITEMS), 256, 0, c->stream>>>(
             c->keysA.p, c->valsA.p, n, c->table.p, (uint32_t)cells, (uint32_t)(n - (c->slab ? c->nDead : 0)),
             c->valsB.p, c->keysB.p);
     }
