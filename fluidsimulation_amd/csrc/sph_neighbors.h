@@ -167,7 +167,7 @@ struct NbArgs {
     int queue;                // index of this launch's work-queue counter (two words: blocks, cells)
     BlockHdr *blockList;
     int blockCap;
-    int2 *gcellList;          // cells for the global-memory path: tile, x | y << 8 | z << 16
+    int2 *gcellList;          // crowded cells (process_cell_chunked): tile (-1: unused entry), x | y << 8 | z << 16
     int gcellCap;
     uint4 *pool;              // plans
     uint32_t poolCap;         // in 16-byte units
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(NB_PTHREADS) __attribute__((amdgpu_waves_per_eu(NB_
         PT_MARK(1);
         // The largest blocks whose 27-cell halo fits the LDS image: the whole tile (halo 144
         // cells for 32), else per y-half a 4x2x2 block (96 for 16), else per layer 4x2x1 (72 for
-        // 8), 2x2x1 (48 for 4), single cells (27 for 1), else the global-memory path.  Blocks stay
+        // 8), 2x2x1 (48 for 4), single cells (27 for 1), else the crowded-cell path.  Blocks stay
         // long in x, the direction of the row windows.  One instantiation per shape.
         if (plan_block<SPH_TX, SPH_TY, SPH_TZ>(sh, A, tileCur, 0, 0, 0, la PT_ARG)) continue;
         for (int yh = 0; yh < 2; yh++) {
@@ -896,7 +896,7 @@ template <bool FORCE, bool COUNT> struct NbShared {
     uint32_t gnext; // place in the crowded-cell list (its own word: `next` may still be read by a wave that leaves the block loop)
     uint32_t gpoolAt, gpoolEnd; // this workgroup's piece of the pool for hit masks of crowded cells
 };
-static_assert(sizeof(HaloTab) <= NB_PLANMAX, "the global-memory path keeps the tile's halo in the plan area");
+static_assert(sizeof(HaloTab) <= NB_PLANMAX, "the crowded-cell path keeps the tile's halo in the plan area");
 static_assert(NB_CAP < 2048, "PlanShared::slot16 holds record indices in 11 bits");
 
 // one planned block.  MULTI: the scene has more than one material (else no target's material index
@@ -1449,8 +1449,8 @@ __device__ void process_cell_chunked(NbShared<FORCE, COUNT> &sh, const HaloTab &
 // with chunk b, the chunks behind the first gridDim.x come from one device-wide counter (a single
 // word serves about 88 returning atomics per microsecond on this chip, so one atomic per block
 // would cost most of a millisecond per launch by itself); the next chunk is requested while the
-// current one is being processed.  Then the cells of the global-memory path, one at a time, dealt
-// the same way.
+// current one is being processed.  Then the crowded cells (process_cell_chunked), NB_GQUEUE per
+// request, dealt the same way.
 template <bool FORCE, bool COUNT, bool MULTI>
 // second launch bound = waves per SIMD the register allocation must allow (what the LDS allows)
 __global__ __launch_bounds__(FORCE ? NB_FTHREADS : NB_DTHREADS)

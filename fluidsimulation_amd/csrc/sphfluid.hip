@@ -220,7 +220,7 @@ struct SphCtx {
     DevBuf<uint32_t> tileList, tileCtl; // non-empty tiles; NB_CTL_* words and work-queue counters
     int nbGrid[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // persistent grid of k_neighbors<FORCE,COUNT,MULTI>
     int queueNext = NB_CTL_QUEUE0;       // next unused pair of work-queue words of tileCtl
-    // neighbour plan (k_plan): block list, plans, cells of the global-memory path
+    // neighbour plan (k_plan): block list, plans, crowded cells
     DevBuf<BlockHdr> blockList;
     DevBuf<int2> gcellList;
     DevBuf<uint32_t> gmaskOff; // one word per entry of gcellList
@@ -1567,7 +1567,7 @@ template <bool FORCE, bool COUNT, bool MULTI> static int launch_neighbors_m(SphC
         c->queueNext = NB_CTL_QUEUE0;
     }
     A.queue = c->queueNext;
-    c->queueNext += 2; // blocks, cells of the global-memory path
+    c->queueNext += 2; // blocks, crowded cells
     k_neighbors<FORCE, COUNT, MULTI><<<std::min(grid, std::max(c->grid.tiles, 1)), threads, 0, c->stream>>>(A);
     HIPCHK(c, hipGetLastError());
     return SPH_OK;
