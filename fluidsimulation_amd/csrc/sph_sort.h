@@ -198,33 +198,50 @@ __global__ void k_map_table(const uint32_t *__restrict__ skeys, int n, int2 *__r
     }
 }
 
-// Compacts the non-empty tiles into tileList, tileCtl[0] = their number.  One atomic per block
-// (a single contended counter per tile costs 12 ns each); the order of the list is arbitrary, it
-// only decides which workgroup takes which tile.
+// Compacts the non-empty tiles into tileList, tileCtl[0] = their number.  One atomic per block of
+// 1024 tiles (a single word serves 88 returning atomics per microsecond: with one per 256 tiles the
+// atomics were the whole kernel on C3); the order of the list is arbitrary, it only decides which
+// workgroup takes which tile.
+#define TL_ITEMS 4
 __global__ __launch_bounds__(256) void k_tile_list(const int2 *__restrict__ ttable, int tiles,
                                                    uint32_t *__restrict__ tileList,
                                                    uint32_t *__restrict__ tileCtl)
 {
-    __shared__ uint32_t waveCount[4], base;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    bool full = false;
-    if (t < tiles) {
-        const int2 r = ttable[t];
-        full = r.y > r.x;
-    }
-    const unsigned long long m = __ballot(full);
+    __shared__ uint32_t waveCount[TL_ITEMS][4], base;
     const int w = threadIdx.x >> 6;
-    if (lane_id() == 0) waveCount[w] = (uint32_t)__popcll(m);
+    bool full[TL_ITEMS];
+    unsigned long long m[TL_ITEMS];
+#pragma unroll
+    for (int j = 0; j < TL_ITEMS; j++) {
+        const int t = (blockIdx.x * TL_ITEMS + j) * 256 + (int)threadIdx.x;
+        full[j] = false;
+        if (t < tiles) {
+            const int2 r = ttable[t];
+            full[j] = r.y > r.x;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TL_ITEMS; j++) {
+        m[j] = __ballot(full[j]);
+        if (lane_id() == 0) waveCount[j][w] = (uint32_t)__popcll(m[j]);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t total = waveCount[0] + waveCount[1] + waveCount[2] + waveCount[3];
+        uint32_t total = 0;
+        for (int j = 0; j < TL_ITEMS; j++)
+            for (int i = 0; i < 4; i++) total += waveCount[j][i];
         base = total ? atomicAdd(&tileCtl[0], total) : 0u;
     }
     __syncthreads();
-    if (full) {
-        uint32_t off = base + (uint32_t)mbcnt64(m);
-        for (int i = 0; i < w; i++) off += waveCount[i];
-        tileList[off] = (uint32_t)t;
+#pragma unroll
+    for (int j = 0; j < TL_ITEMS; j++) {
+        if (full[j]) {
+            uint32_t off = base + (uint32_t)mbcnt64(m[j]);
+            for (int jj = 0; jj < j; jj++)
+                for (int i = 0; i < 4; i++) off += waveCount[jj][i];
+            for (int i = 0; i < w; i++) off += waveCount[j][i];
+            tileList[off] = (uint32_t)((blockIdx.x * TL_ITEMS + j) * 256 + (int)threadIdx.x);
+        }
     }
 }
 

@@ -1363,7 +1363,7 @@ int sph_map_table(SphCtx *c)
     c->havePlan = c->haveMasks = false;
     k_map_table<<<blocks_for(c->n, 256), 256, 0, c->stream>>>(c->sortedKeys, c->n, c->table.p,
                                                               c->ttable.p);
-    k_tile_list<<<blocks_for(c->grid.tiles, 256), 256, 0, c->stream>>>(
+    k_tile_list<<<blocks_for(c->grid.tiles, 256 * TL_ITEMS), 256, 0, c->stream>>>(
         c->ttable.p, c->grid.tiles, c->tileList.p, c->tileCtl.p);
     HIPCHK(c, hipGetLastError());
     c->haveTable = true;
@@ -1412,7 +1412,7 @@ static int sort_and_table(SphCtx *c)
         k_cell_scan_sums<<<1, RS_THREADS, 0, c->stream>>>(c->cellSums.p, nb);
         k_cell_table<<<nb, 256, 0, c->stream>>>((const uint4 *)c->cellCounts.p, nquads, c->cellSums.p, cells,
                                                 c->table.p, c->ttable.p);
-        k_tile_list<<<blocks_for(c->grid.tiles, 256), 256, 0, c->stream>>>(
+        k_tile_list<<<blocks_for(c->grid.tiles, 256 * TL_ITEMS), 256, 0, c->stream>>>(
             c->ttable.p, c->grid.tiles, c->tileList.p, c->tileCtl.p);
     }
     {
