@@ -22,7 +22,9 @@ __global__ __launch_bounds__(256) void k_slab_pack(
     const float4 *__restrict__ posm, const float4 *__restrict__ velq,
     const uint32_t *__restrict__ mat, uint32_t *__restrict__ oid, int n, float lo, float hi,
     float halo, float4 *__restrict__ left, float4 *__restrict__ right, int cap,
-    uint32_t *__restrict__ counters)
+    uint32_t *__restrict__ counters,
+    uint32_t *__restrict__ keys /* nullable, not COUNT_ONLY: this step's cell keys (saves k_slab_keys) */,
+    GridDesc g)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool sendL = false, sendR = false, moveL = false, moveR = false;
@@ -32,6 +34,7 @@ __global__ __launch_bounds__(256) void k_slab_pack(
         id = oid[i];
         if (id & SPH_ID_GHOST) {
             if (!COUNT_ONLY && !(id & SPH_ID_DEAD)) oid[i] = id | SPH_ID_DEAD;
+            if (!COUNT_ONLY && keys) keys[i] = (uint32_t)g.cells; // dead: sorted to the end
         } else {
             p = posm[i];
             moveL = p.x < lo;
@@ -39,6 +42,9 @@ __global__ __launch_bounds__(256) void k_slab_pack(
             sendL = p.x < lo + halo;
             sendR = p.x >= hi - halo;
             if (!COUNT_ONLY && (moveL || moveR)) oid[i] = id | SPH_ID_GHOST; // this step's ghost
+            if (!COUNT_ONLY && keys)
+                keys[i] = dense_key(quantize1(p.x, g.cellSize), quantize1(p.y, g.cellSize),
+                                    quantize1(p.z, g.cellSize), g);
         }
     }
 #pragma unroll
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) void k_slab_pack(
 __global__ void k_slab_import(const float4 *__restrict__ recs, int count,
                               const Mat *__restrict__ mats, int nmats, float4 *__restrict__ posm,
                               float4 *__restrict__ velq, uint32_t *__restrict__ mat,
-                              uint32_t *__restrict__ oid)
+                              uint32_t *__restrict__ oid, uint32_t *__restrict__ keys, GridDesc g)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -79,6 +85,8 @@ __global__ void k_slab_import(const float4 *__restrict__ recs, int count,
     velq[i] = make_float4(b.x, b.y, b.z, 0.f);
     mat[i] = m;
     oid[i] = __float_as_uint(b.w) & ~SPH_ID_DEAD;
+    keys[i] = dense_key(quantize1(a.x, g.cellSize), quantize1(a.y, g.cellSize),
+                        quantize1(a.z, g.cellSize), g);
 }
 
 // upload with caller-given ids and material indices
@@ -97,7 +105,8 @@ __global__ void k_slab_pack_fluid(const float *__restrict__ pos3, const float *_
     oid[i] = ids[i] & SPH_ID_MASK;
 }
 
-// cell keys with the dead records sent to the end of the sort
+// cell keys with the dead records sent to the end of the sort (a step that was not preceded by a
+// pack: the pack and import kernels write the same keys, they hold the positions)
 __global__ void k_slab_keys(const float4 *__restrict__ posm, const uint32_t *__restrict__ oid,
                             int n, GridDesc g, uint32_t *__restrict__ keys)
 {

@@ -226,6 +226,7 @@ struct SphCtx {
     DevBuf<uint32_t> gmaskOff; // one word per entry of gcellList
     int planGrid = 1;          // workgroups of the last k_plan launch
     DevBuf<uint32_t> cellCounts, cellSums; // counting sort of the step entry points (sph_sort.h)
+    bool slabKeys = false;     // slab mode: keysA holds this step's keys (written by the pack and import kernels)
     bool radixInSteps = false;  // SPHFLUID_STEP_SORT=radix: the step entry points sort like sph_radix_sort
     DevBuf<uint4> pool;
     bool havePlan = false;
@@ -607,6 +608,7 @@ int key_bits(int cells)
 
 void set_grid(SphCtx *c, const int origin[3], const int dims[3], float cellSize)
 {
+    c->slabKeys = false; // (keys of another grid)
     GridDesc g;
     g.ox = origin[0]; g.oy = origin[1]; g.oz = origin[2];
     // dimensions are rounded up to whole tiles
@@ -1300,6 +1302,12 @@ int sph_hash_position(SphCtx *c, const SphParams *p)
     if (rc) return rc;
     rc = ensure_debug(c);
     if (rc) return rc;
+    if (c->slab && c->slabKeys) { // the pack and import kernels of this step's exchange have written them
+        c->slabKeys = false;
+        c->haveKeys = true;
+        c->haveSort = c->haveTable = c->ordered = false;
+        return SPH_OK;
+    }
     StageTimer t(c, SPH_T_KEYS);
     const int N = c->n, cur = c->cur;
     if (c->slab)
@@ -1627,6 +1635,7 @@ static int launch_apply_integrate(SphCtx *c, const SphParams *p, bool apply, boo
 {
     const int N = c->n, cur = c->cur;
     const int nb = blocks_for(N, 256);
+    if (integrate) c->slabKeys = false; // (the positions change)
 #define LAUNCH_AI(A, I)                                                                          \
     k_apply_integrate<A, I><<<nb, 256, 0, c->stream>>>(                                          \
         c->posm[cur].p, c->velq[cur].p, c->force.p, c->rho.p,                                    \
@@ -2198,6 +2207,7 @@ int sph_slab_upload(SphCtx *c, const float *pos, const float *vel, const uint32_
     rc = upload_mats(c, c->matRate > 0.f ? c->matRate : 4.0f);
     if (rc) return rc;
     c->slab = true;
+    c->slabKeys = false;
     c->slabCap = capacity;
     c->n = N;
     c->nOwned = N;
@@ -2252,11 +2262,11 @@ int sph_slab_pack(SphCtx *c, float xlo, float xhi, float halo, void *left_dev, v
         if (pass == 0)
             k_slab_pack<true><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
                 c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
-                nullptr, nullptr, 0, c->slabCounters.p);
+                nullptr, nullptr, 0, c->slabCounters.p, nullptr, c->grid);
         else
             k_slab_pack<false><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
                 c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
-                (float4 *)left_dev, (float4 *)right_dev, capRecords, c->slabCounters.p);
+                (float4 *)left_dev, (float4 *)right_dev, capRecords, c->slabCounters.p, c->keysA.p, c->grid);
         HIPCHK(c, hipGetLastError());
         if (pass == 0) {
             HIPCHK(c, hipMemcpyAsync(h, c->slabCounters.p, 16, hipMemcpyDeviceToHost, c->stream));
@@ -2276,6 +2286,7 @@ int sph_slab_pack(SphCtx *c, float xlo, float xhi, float halo, void *left_dev, v
     c->nDead += c->nGhost;
     c->nGhost = moved;
     c->nOwned -= moved;
+    c->slabKeys = true; // (the pack pass has written the keys of every resident record)
     return SPH_OK;
 }
 
@@ -2299,10 +2310,11 @@ int sph_slab_import(SphCtx *c, const void *records_dev, int32_t count, int32_t t
         if (!rc) rc = ensure_fluid(c, (int)want);
         if (rc) return rc;
         c->slabCap = (int)want;
+        c->slabKeys = false; // (the key buffer has been reallocated: k_slab_keys for this step)
     }
     k_slab_import<<<blocks_for(count, 256), 256, 0, c->stream>>>(
         (const float4 *)records_dev, count, c->dmats.p, (int)c->mats.size(), c->posm[cur].p + n,
-        c->velq[cur].p + n, c->mat[cur].p + n, c->oid[cur].p + n);
+        c->velq[cur].p + n, c->mat[cur].p + n, c->oid[cur].p + n, c->keysA.p + n, c->grid);
     HIPCHK(c, hipGetLastError());
     c->rhoInOrder = false;
     c->n += count;
@@ -2488,7 +2500,7 @@ int sph_slab_exchange(SphCtx *c, float xlo, float xhi, float halo, int32_t count
     if (c->n > 0)
         k_slab_pack<true><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
             c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
-            nullptr, nullptr, 0, c->slabCounters.p);
+            nullptr, nullptr, 0, c->slabCounters.p, nullptr, c->grid);
     HIPCHK(c, hipGetLastError());
     // 2. the counters go to both neighbours as they are: the left one reads words 0 and 2 (records,
     // transfers towards it), the right one words 1 and 3
@@ -2549,8 +2561,9 @@ int sph_slab_exchange(SphCtx *c, float xlo, float xhi, float halo, int32_t count
     if (c->n > 0)
         k_slab_pack<false><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
             c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
-            c->xsend[0].p, c->xsend[1].p, (int)cap, c->slabCounters.p);
+            c->xsend[0].p, c->xsend[1].p, (int)cap, c->slabCounters.p, c->keysA.p, c->grid);
     HIPCHK(c, hipGetLastError());
+    c->slabKeys = true; // (and the imports below add the keys of what arrives)
     const int moved = (int)((hasL ? h[2] : 0u) + (hasR ? h[3] : 0u));
     // (particles beyond an outer rank's open side are not sent anywhere: xlo / xhi are infinite there)
     c->nDead += c->nGhost;
