@@ -213,7 +213,9 @@ __device__ __forceinline__ float dot3f(const float *a, const float *b)
     return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
 }
 
-template <bool APPLY, bool INTEGRATE>
+// SLABCOUNT: also count what the next slab exchange will send (its own instantiation: the plain
+// resident loop must not pay for the arguments)
+template <bool APPLY, bool INTEGRATE, bool SLABCOUNT>
 __global__ __launch_bounds__(256) void k_apply_integrate(
     float4 *__restrict__ posm, float4 *__restrict__ velq, const float4 *__restrict__ force,
     const float *__restrict__ rho, const uint32_t *__restrict__ mat,
@@ -223,6 +225,9 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
     const float4 *__restrict__ chunkAabb /* 2 per chunk of SPH_BOX_CHUNK boxes */,
     const uint32_t *__restrict__ slabFlags /* slab mode: ids with the ghost bit, else nullptr */,
     uint32_t *__restrict__ nextKeys /* nullable: the next step's cell keys (saves k_keys) */,
+    uint32_t *__restrict__ slabNext /* nullable, slab mode: the counters of the NEXT exchange (records for the
+                                       left / right neighbour, transfers left / right) if its cuts are ... */,
+    float slabLo, float slabHi, float slabHalo /* ... these: saves the counting pass of k_slab_pack */,
     GridDesc grid)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -506,6 +511,23 @@ __global__ __launch_bounds__(256) void k_apply_integrate(
         if (INTEGRATE && nextKeys)
             nextKeys[i] = dense_key(quantize1(x[0], grid.cellSize), quantize1(x[1], grid.cellSize),
                                     quantize1(x[2], grid.cellSize), grid);
+    }
+    if (INTEGRATE && SLABCOUNT) { // (the whole wave comes here)
+        // what k_slab_pack<true> would count from the positions just written: owned records only
+        // (a ghost is not sent on), same comparisons on the same floats
+        const bool cand = live && owned;
+        const bool moveL = cand && x[0] < slabLo, moveR = cand && x[0] >= slabHi;
+        const bool sendL = cand && x[0] < slabLo + slabHalo, sendR = cand && x[0] >= slabHi - slabHalo;
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const unsigned long long m = __ballot(side ? sendR : sendL);
+            if (m == 0) continue; // wave-uniform
+            const unsigned long long mm = __ballot(side ? moveR : moveL);
+            if (lane_id() == 0) {
+                atomicAdd(&slabNext[side], (uint32_t)__popcll(m));
+                if (mm) atomicAdd(&slabNext[2 + side], (uint32_t)__popcll(mm));
+            }
+        }
     }
 }
 

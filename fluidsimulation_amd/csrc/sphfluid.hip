@@ -226,6 +226,12 @@ struct SphCtx {
     DevBuf<uint32_t> gmaskOff; // one word per entry of gcellList
     int planGrid = 1;          // workgroups of the last k_plan launch
     DevBuf<uint32_t> cellCounts, cellSums; // counting sort of the step entry points (sph_sort.h)
+    // slab mode: the integrate kernel counts what the next exchange will send, for the cuts of the
+    // last one (fixed cuts: the exchange then skips its counting pass)
+    DevBuf<uint32_t> slabNext;
+    float expectLo = 0.f, expectHi = 0.f, expectHalo = -1.f;
+    bool nextCounts = false;   // slabNext holds the counters for (expectLo, expectHi, expectHalo)
+    bool slabCountPass = false; // SPHFLUID_SLAB_COUNT_PASS=1: always count in a pass of its own (tests)
     bool slabKeys = false;     // slab mode: keysA holds this step's keys (written by the pack and import kernels)
     bool radixInSteps = false;  // SPHFLUID_STEP_SORT=radix: the step entry points sort like sph_radix_sort
     DevBuf<uint4> pool;
@@ -926,6 +932,7 @@ int sph_create(const SphConfig *cfg, SphCtx **out)
     c->pinHost = cfg && cfg->pinHostArrays;
     if (const char *e = getenv("SPHFLUID_POOL_LIMIT")) c->poolLimit = atoll(e);
     if (const char *e = getenv("SPHFLUID_STEP_SORT")) c->radixInSteps = strcmp(e, "radix") == 0;
+    if (const char *e = getenv("SPHFLUID_SLAB_COUNT_PASS")) c->slabCountPass = atoi(e) != 0;
     if (const char *e = getenv("SPHFLUID_CAP1")) c->cap1 = std::max(0, std::min(NB_CAP, atoi(e)));
     *out = c;
     return SPH_OK;
@@ -1636,16 +1643,26 @@ static int launch_apply_integrate(SphCtx *c, const SphParams *p, bool apply, boo
     const int N = c->n, cur = c->cur;
     const int nb = blocks_for(N, 256);
     if (integrate) c->slabKeys = false; // (the positions change)
-#define LAUNCH_AI(A, I)                                                                          \
-    k_apply_integrate<A, I><<<nb, 256, 0, c->stream>>>(                                          \
+    uint32_t *slabNext = nullptr;
+    c->nextCounts = false;
+    if (integrate && c->slab && c->expectHalo >= 0.f && c->slabNext.p) {
+        HIPCHK(c, hipMemsetAsync(c->slabNext.p, 0, 16, c->stream));
+        slabNext = c->slabNext.p;
+        c->nextCounts = true;
+    }
+#define LAUNCH_AI(A, I, S)                                                                       \
+    k_apply_integrate<A, I, S><<<nb, 256, 0, c->stream>>>(                                          \
         c->posm[cur].p, c->velq[cur].p, c->force.p, c->rho.p,                                    \
         c->matAllZero ? nullptr : c->mat[cur].p, c->dmats.p, N,                                  \
         p->dt, c->devBoxes.p, c->nboxes, p->particleRestitution, c->bodyImpulse.p,               \
         c->boxAabb.p, c->chunkAabb.p,                                                            \
-        c->slab ? c->oid[cur].p : nullptr, nextKeys ? c->keysA.p : nullptr, c->grid)
-    if (apply && integrate) LAUNCH_AI(true, true);
-    else if (apply) LAUNCH_AI(true, false);
-    else LAUNCH_AI(false, true);
+        c->slab ? c->oid[cur].p : nullptr, nextKeys ? c->keysA.p : nullptr,                      \
+        slabNext, c->expectLo, c->expectHi, c->expectHalo, c->grid)
+    if (apply && integrate && slabNext) LAUNCH_AI(true, true, true);
+    else if (apply && integrate) LAUNCH_AI(true, true, false);
+    else if (apply) LAUNCH_AI(true, false, false);
+    else if (slabNext) LAUNCH_AI(false, true, true);
+    else LAUNCH_AI(false, true, false);
 #undef LAUNCH_AI
     HIPCHK(c, hipGetLastError());
     return SPH_OK;
@@ -2195,6 +2212,7 @@ int sph_slab_upload(SphCtx *c, const float *pos, const float *vel, const uint32_
     if (!rc) rc = ensure(c, c->io3b, (size_t)3 * std::max(N, 1));
     if (!rc) rc = ensure(c, c->ioU, (size_t)2 * std::max(N, 1));
     if (!rc) rc = ensure(c, c->slabCounters, 4, false);
+    if (!rc) rc = ensure(c, c->slabNext, 4, false);
     if (rc) return rc;
     // the material table is the caller's, in the caller's order (the same on every rank)
     c->matKeys.clear();
@@ -2208,6 +2226,8 @@ int sph_slab_upload(SphCtx *c, const float *pos, const float *vel, const uint32_
     if (rc) return rc;
     c->slab = true;
     c->slabKeys = false;
+    c->nextCounts = false;
+    c->expectHalo = -1.f;
     c->slabCap = capacity;
     c->n = N;
     c->nOwned = N;
@@ -2243,6 +2263,32 @@ int sph_slab_upload(SphCtx *c, const float *pos, const float *vel, const uint32_
     return SPH_OK;
 }
 
+// The counters of an exchange with these cuts: counted by the integrate kernel of the step before
+// when the cuts are the ones of the last exchange (fixed cuts), else by a pass of their own
+// (k_slab_pack<true>: nothing is written, no record changes state).  Leaves them in
+// c->slabCounters; remembers the cuts for the next integrate.
+static int slab_count(SphCtx *c, float xlo, float xhi, float halo)
+{
+    const int cur = c->cur;
+    const bool ready = c->nextCounts && !c->slabCountPass && xlo == c->expectLo && xhi == c->expectHi &&
+                       halo == c->expectHalo;
+    c->nextCounts = false;
+    c->expectLo = xlo;
+    c->expectHi = xhi;
+    c->expectHalo = halo;
+    if (ready) {
+        HIPCHK(c, hipMemcpyAsync(c->slabCounters.p, c->slabNext.p, 16, hipMemcpyDeviceToDevice, c->stream));
+        return SPH_OK;
+    }
+    HIPCHK(c, hipMemsetAsync(c->slabCounters.p, 0, 16, c->stream));
+    if (c->n > 0)
+        k_slab_pack<true><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
+            nullptr, nullptr, 0, c->slabCounters.p, nullptr, c->grid);
+    HIPCHK(c, hipGetLastError());
+    return SPH_OK;
+}
+
 int sph_slab_pack(SphCtx *c, float xlo, float xhi, float halo, void *left_dev, void *right_dev,
                   int32_t capRecords, int32_t counts[4])
 {
@@ -2257,26 +2303,24 @@ int sph_slab_pack(SphCtx *c, float xlo, float xhi, float halo, void *left_dev, v
     // call again
     const int cur = c->cur;
     uint32_t h[4] = {0, 0, 0, 0};
-    for (int pass = 0; pass < 2 && c->n > 0; pass++) {
-        HIPCHK(c, hipMemsetAsync(c->slabCounters.p, 0, 16, c->stream));
-        if (pass == 0)
-            k_slab_pack<true><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
-                c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
-                nullptr, nullptr, 0, c->slabCounters.p, nullptr, c->grid);
-        else
-            k_slab_pack<false><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
-                c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
-                (float4 *)left_dev, (float4 *)right_dev, capRecords, c->slabCounters.p, c->keysA.p, c->grid);
-        HIPCHK(c, hipGetLastError());
-        if (pass == 0) {
-            HIPCHK(c, hipMemcpyAsync(h, c->slabCounters.p, 16, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            for (int i = 0; i < 4; i++) counts[i] = (int32_t)h[i];
-            if (h[0] > (uint32_t)capRecords || h[1] > (uint32_t)capRecords)
-                return fail(c, SPH_E_TOOLARGE, "exchange buffer too small: %u / %u records, "
-                            "capacity %d (nothing was packed; counts[] holds what is needed)",
-                            h[0], h[1], capRecords);
+    if (c->n > 0) {
+        if (int rc = slab_count(c, xlo, xhi, halo)) return rc;
+        HIPCHK(c, hipMemcpyAsync(h, c->slabCounters.p, 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < 4; i++) counts[i] = (int32_t)h[i];
+        if (h[0] > (uint32_t)capRecords || h[1] > (uint32_t)capRecords) {
+            // (the counts stay good for the caller's second attempt with larger buffers)
+            c->nextCounts = true;
+            HIPCHK(c, hipMemcpyAsync(c->slabNext.p, c->slabCounters.p, 16, hipMemcpyDeviceToDevice, c->stream));
+            return fail(c, SPH_E_TOOLARGE, "exchange buffer too small: %u / %u records, "
+                        "capacity %d (nothing was packed; counts[] holds what is needed)",
+                        h[0], h[1], capRecords);
         }
+        HIPCHK(c, hipMemsetAsync(c->slabCounters.p, 0, 16, c->stream));
+        k_slab_pack<false><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
+            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
+            (float4 *)left_dev, (float4 *)right_dev, capRecords, c->slabCounters.p, c->keysA.p, c->grid);
+        HIPCHK(c, hipGetLastError());
     }
     if (c->n <= 0)
         for (int i = 0; i < 4; i++) counts[i] = 0;
@@ -2317,6 +2361,7 @@ int sph_slab_import(SphCtx *c, const void *records_dev, int32_t count, int32_t t
         c->velq[cur].p + n, c->mat[cur].p + n, c->oid[cur].p + n, c->keysA.p + n, c->grid);
     HIPCHK(c, hipGetLastError());
     c->rhoInOrder = false;
+    c->nextCounts = false; // (records the integrate kernel has not seen)
     c->n += count;
     c->nOwned += transfers;
     c->nGhost += count - transfers;
@@ -2495,13 +2540,8 @@ int sph_slab_exchange(SphCtx *c, float xlo, float xhi, float halo, int32_t count
     const int cur = c->cur, left = c->commRank - 1, right = c->commRank + 1;
     const bool hasL = left >= 0, hasR = right < c->commWorld;
     // 1. what this rank will send (no record changes state yet)
-    HIPCHK(c, hipMemsetAsync(c->slabCounters.p, 0, 16, c->stream));
     HIPCHK(c, hipMemsetAsync(c->xhdr.p, 0, 32, c->stream));
-    if (c->n > 0)
-        k_slab_pack<true><<<blocks_for(c->n, 256), 256, 0, c->stream>>>(
-            c->posm[cur].p, c->velq[cur].p, c->mat[cur].p, c->oid[cur].p, c->n, xlo, xhi, halo,
-            nullptr, nullptr, 0, c->slabCounters.p, nullptr, c->grid);
-    HIPCHK(c, hipGetLastError());
+    if (int rc0 = slab_count(c, xlo, xhi, halo)) return rc0;
     // 2. the counters go to both neighbours as they are: the left one reads words 0 and 2 (records,
     // transfers towards it), the right one words 1 and 3
     if (hasL || hasR) {

@@ -233,6 +233,47 @@ def test_native_rccl_exchange_world_of_one():
 
 
 @pytest.mark.gpu
+def test_counts_of_the_next_exchange_come_from_the_integrate_kernel():
+    """With the cuts of the last exchange unchanged, the counters of the next one (records and
+    transfers per side) are accumulated by the integrate kernel and the counting pass of
+    k_slab_pack is skipped; SPHFLUID_SLAB_COUNT_PASS=1 forces that pass.  Cuts inside the fluid,
+    nobody to send to: what the pack reports and what stays resident must be the same step by
+    step, also when the cuts change in between (then the pass of its own runs)."""
+    import os
+    import numpy as np
+    import torch
+    from fluidsimulation_amd import native, scene
+    sc = scene.dam_break(12, 10, 8, jitter_seed=3)
+    mats = np.array([[0.25, 1000, 256, 512, 1 / 125]], np.float32)
+    idx = np.zeros(sc.n, np.uint32)
+    ids = np.arange(sc.n, dtype=np.uint32)
+    p = native.make_params(sc.grid_size)
+    cuts = [(2.0, 4.0)] * 6 + [(2.5, 4.5)] * 3 + [(2.0, 4.0)] * 6
+    runs = []
+    for force_pass in (False, True):
+        if force_pass:
+            os.environ["SPHFLUID_SLAB_COUNT_PASS"] = "1"
+        try:
+            with native.Context(device=0) as ctx:
+                ctx.set_boundary(sc.bpos, sc.bparams)
+                ctx.slab_upload(sc.pos, sc.vel, idx, ids, mats, sc.grid_size, capacity=2 * sc.n)
+                left = torch.zeros((sc.n, 8), dtype=torch.float32, device="cuda:0")
+                right = torch.zeros_like(left)
+                log = []
+                for lo, hi in cuts:
+                    log.append(tuple(ctx.slab_pack(lo, hi, 2.0, left.data_ptr(), right.data_ptr(), sc.n)))
+                    ctx.step_resident(p, 1)
+                    log.append(tuple(sorted(ctx.slab_counts().items())))
+                runs.append((log, ctx.slab_download()))
+        finally:
+            os.environ.pop("SPHFLUID_SLAB_COUNT_PASS", None)
+    assert runs[0][0] == runs[1][0]
+    assert any(c[0] > 0 and c[2] > 0 for c in runs[0][0][::2])   # records were sent and some moved
+    for a, b in zip(runs[0][1], runs[1][1]):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3])
 def test_native_rccl_exchange_between_gpus(world, tmp_path):
     """sph_slab_exchange between real devices: one rank per GPU, records over the library's own
